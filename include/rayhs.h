@@ -1,0 +1,220 @@
+/*
+ * rayhs.h -- C ABI of librayhs_hip.so, the MI355X (gfx950) replacement for the
+ * per-pixel trace loop of oilandrust/rayhs.
+ *
+ * The reference has no FFI; the seam this ABI replaces is the pure function
+ *     rayTrace :: Rendering -> Image                      (src/RayHs.hs:161-166)
+ * i.e. the closure handed to generatePixels (src/Image.hs:34-36).  A host (the
+ * reference's Haskell Descriptors/JSON/Scene code, or the C++ host shipped here)
+ * flattens its immutable Scene (src/Scene.hs:8-10) into the SoA arrays of
+ * rayhs_scene_desc, hands them over once with rayhs_scene_create, then calls
+ * rayhs_render* per frame.  INTEGRATION.md shows the `foreign import ccall`
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes only; 0 on success, negative
+ * rayhs_status otherwise; no exceptions cross the boundary; the library owns
+ * opaque handles, the caller owns every buffer it passes in (inputs are copied
+ * by rayhs_scene_create); a handle may be used from one thread at a time;
+ * rayhs_last_error() is thread-local and valid until the next call on the
+ * thread.  There is no CPU fallback: without a HIP device every compute entry
+ * point fails with RAYHS_ERR_NO_DEVICE.
+ */
+#ifndef RAYHS_H
+#define RAYHS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAYHS_ABI_VERSION 1
+
+typedef enum {
+    RAYHS_OK = 0,
+    RAYHS_ERR_INVALID = -1,    /* bad argument / inconsistent scene description */
+    RAYHS_ERR_NO_DEVICE = -2,  /* no usable HIP device */
+    RAYHS_ERR_HIP = -3,        /* a HIP runtime call failed */
+    RAYHS_ERR_IO = -4,         /* file could not be read / written */
+    RAYHS_ERR_PARSE = -5,      /* "Failed to read scene" (src/RayHs.hs:226) or OBJ parse error */
+    RAYHS_ERR_UNSUPPORTED = -6 /* e.g. tree deeper than the per-lane LDS stack */
+} rayhs_status;
+
+/* Geometry constructors in scene order (src/Geometry.hs:62-63, src/KDTree.hs:59-61) */
+enum { RAYHS_GEOM_PLANE = 0, RAYHS_GEOM_SPHERE = 1, RAYHS_GEOM_MESH = 2 };
+/* Material constructors (src/Material.hs:13-19) */
+enum { RAYHS_MAT_MIRROR = 0, RAYHS_MAT_DIFFUSE = 1, RAYHS_MAT_PLASTIC = 2, RAYHS_MAT_EMMIT = 3,
+       RAYHS_MAT_TRANSPARENT = 4, RAYHS_MAT_SHOWNORMAL = 5, RAYHS_MAT_SHOWUV = 6 };
+/* ColorMap constructors (src/ColorMap.hs:11-16) */
+enum { RAYHS_CMAP_FLAT = 0, RAYHS_CMAP_CHECKER = 1, RAYHS_CMAP_TEXTURE = 2 };
+/* Light constructors (src/Light.hs:8-10) */
+enum { RAYHS_LIGHT_DIRECTIONAL = 0, RAYHS_LIGHT_POINT = 1 };
+/* Projection constructors (src/Projection.hs:10-15) */
+enum { RAYHS_PROJ_ORTHOGRAPHIC = 0, RAYHS_PROJ_PERSPECTIVE = 1 };
+
+/*
+ * Flattened Scene (src/Scene.hs:8-10).  All reals are fp64, as in the
+ * reference (src/Vec.hs:29-31).  Vectors are xyz triples, colours rgb triples.
+ *
+ * Objects keep SCENE ORDER: closest-hit ties are broken by it
+ * (minimumBy, src/RayHs.hs:67-71).  obj_geom_index[i] indexes the plane,
+ * sphere or mesh arrays according to obj_geom_kind[i].  Material arrays are
+ * per object.
+ *
+ * A mesh is the bounding-box tree of src/KDTree.hs:59-61 in any node order:
+ * node k has box node_lo/node_hi[3k..], and either
+ *   inner: node_tri_count[k] < 0, children node_left[k] / node_right[k]
+ *          (-1 = Empty, src/KDTree.hs:61), node_axis[k] = split axis 0..2, or
+ *   leaf : node_tri_count[k] >= 0 triangles starting at node_first_tri[k].
+ * Triangles must be stored so that leaves appear in left-to-right (DFS) order
+ * with the reference's in-leaf order preserved: tie-breaking between equal t
+ * depends on it (src/Geometry.hs:54-57, src/KDTree.hs:113-115).
+ * tri_pos: 9 doubles p0,p1,p2; tri_nrm: 9 doubles n0,n1,n2; tri_uv: 6 doubles.
+ */
+typedef struct rayhs_scene_desc {
+    int32_t n_objects;
+    const int32_t *obj_geom_kind;   /* RAYHS_GEOM_* */
+    const int32_t *obj_geom_index;
+    const int32_t *mat_kind;        /* RAYHS_MAT_* */
+    const double *mat_ior;          /* mirror / plastic / transparent */
+    const double *mat_ce;           /* 3 per object (emmit) */
+    const int32_t *cmap_kind;       /* RAYHS_CMAP_* (diffuse / plastic) */
+    const double *cmap_c1;          /* 3 per object: flat colour or checker color1 */
+    const double *cmap_c2;          /* 3 per object: checker color2 */
+    const double *cmap_size;        /* checker size */
+    const int32_t *tex_w, *tex_h;   /* texture extent per object (0 if none) */
+    const int64_t *tex_offset;      /* first texel (in texels) inside `texels` */
+    int64_t n_texels;
+    const double *texels;           /* 3 doubles per texel, row-major (src/Bitmap.hs:17-18) */
+
+    int32_t n_planes;
+    const double *plane_point, *plane_normal, *plane_tangent; /* 3 each */
+    int32_t n_spheres;
+    const double *sphere_center;    /* 3 each */
+    const double *sphere_radius;
+
+    int32_t n_meshes;
+    const int32_t *mesh_root;       /* root node index, -1 = Empty tree */
+    int32_t n_nodes;
+    const double *node_lo, *node_hi;
+    const int32_t *node_left, *node_right, *node_first_tri, *node_tri_count, *node_axis;
+    int32_t n_tris;
+    const double *tri_pos, *tri_nrm, *tri_uv;
+
+    int32_t n_lights;
+    const int32_t *light_kind;      /* RAYHS_LIGHT_* */
+    const double *light_vec;        /* direction or position, 3 each */
+    const double *light_color;      /* 3 each */
+    const double *light_radius;     /* point lights */
+} rayhs_scene_desc;
+
+/* Camera (src/Projection.hs:17-20) + Projection (src/Projection.hs:10-15).
+ * proj_width/proj_height/near are carried but unused, as in the reference
+ * (src/Projection.hs:34). */
+typedef struct rayhs_camera {
+    double position[3], target[3], up[3];
+    int32_t proj_kind;  /* RAYHS_PROJ_* */
+    double fovy, proj_width, proj_height, near_;
+} rayhs_camera;
+
+/* Output element types. F64 carries the reference's Double colours unchanged;
+ * F32 is the 12 B/pixel framebuffer of SURVEY.md 8(d); I16 is toIntC
+ * (src/Image.hs:54-55) evaluated on the fp64 value, saturated to int16. */
+enum { RAYHS_OUT_F32 = 0, RAYHS_OUT_F64 = 1, RAYHS_OUT_I16 = 2 };
+
+/* flags */
+#define RAYHS_FLAG_EXACT      1u /* kernels built with -ffp-contract=off: same fp64 operations as the reference */
+#define RAYHS_FLAG_EXHAUSTIVE 2u /* visit exactly the reference's node set (no ordering, no pruning, no any-hit exit) */
+#define RAYHS_FLAG_COUNT      4u /* instrumented run: fill the work counters of rayhs_stats */
+
+/* Rendering (src/RayHs.hs:41-45) plus the tiling needed to shard a frame.
+ * Rows row0 <= y < row1 are considered; of those this call renders the rows
+ * whose stripe index ((y - row0) / stripe_rows) % stripe_count == stripe_rank.
+ * Rendered rows are written compactly in increasing y.  stripe_count = 1
+ * renders the whole range.  spp = 1 is the reference's live path (rayTrace:
+ * pixel-corner rays, no RNG); spp > 1 follows distributedTracePixel
+ * (src/RayHs.hs:173-188) with the build-defined counter sampler and `seed`. */
+typedef struct rayhs_render_params {
+    int32_t width, height, max_depth;
+    int32_t spp;
+    uint64_t seed;
+    int32_t row0, row1;
+    int32_t stripe_rows, stripe_rank, stripe_count;
+    int32_t out_format; /* RAYHS_OUT_* */
+    uint32_t flags;     /* RAYHS_FLAG_* */
+} rayhs_render_params;
+
+/* One ray = one scene query: closestIntersection (src/RayHs.hs:67) or
+ * shadowIntersection (src/RayHs.hs:74).  Work counters are filled only with
+ * RAYHS_FLAG_COUNT. */
+typedef struct rayhs_stats {
+    uint64_t rays_primary, rays_reflect, rays_refract, rays_refract_exit, rays_shadow;
+    uint64_t nodes_tested;  /* rayInterBox evaluations (src/KDTree.hs:39) */
+    uint64_t tris_tested;   /* triangleIntersection evaluations (src/Mesh.hs:59) */
+    uint64_t prims_tested;  /* plane / sphere tests (src/Geometry.hs:68) */
+    uint64_t shaded_hits;   /* irradiance evaluations (src/RayHs.hs:107) */
+    uint64_t pixels;        /* pixels written */
+    double kernel_ms;       /* HIP-event time of the trace kernel of this call (host-buffer entry point only) */
+} rayhs_stats;
+
+typedef struct rayhs_scene rayhs_scene;
+
+const char *rayhs_last_error(void);
+int rayhs_abi_version(void);
+/* number of visible HIP devices (0 if none or the runtime is unusable) */
+int rayhs_device_count(void);
+
+/* Copies the description into device `device` (HBM-resident until destroy). */
+int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayhs_scene **out);
+void rayhs_scene_destroy(rayhs_scene *scene);
+
+/* rows this (params) selects, i.e. the row count of the output buffer */
+int rayhs_render_rows(const rayhs_render_params *params);
+
+/* Renders into a HOST buffer of rayhs_render_rows()*width*3 elements of
+ * params->out_format; synchronous.  stats may be NULL. */
+int rayhs_render(const rayhs_scene *scene, const rayhs_camera *camera,
+                 const rayhs_render_params *params, void *out_host, rayhs_stats *stats);
+
+/* Renders into a DEVICE buffer on the scene's device, asynchronously on
+ * `hip_stream` (a hipStream_t, NULL = default stream).  No host
+ * synchronisation, no allocation: safe to enqueue back to back.  If
+ * d_counters is non-NULL it must point to 16 zeroed uint64 on the device and
+ * RAYHS_FLAG_COUNT must be set. */
+int rayhs_render_device(const rayhs_scene *scene, const rayhs_camera *camera,
+                        const rayhs_render_params *params, void *d_out, void *hip_stream,
+                        uint64_t *d_counters);
+
+/* ---- host preparation (C++ restatement of the reference's L3/L4 host code;
+ * the Haskell host would do this itself and call rayhs_scene_create) -------- */
+
+/* RenderDesc (src/Descriptors.hs:19-23) decoded from JSON (src/JSON.hs:22-141),
+ * with the Scene built (src/Descriptors.hs:39-55: readOBJ, Mesh.transform,
+ * buildKDTree) and flattened.  Mesh/texture paths are opened relative to the
+ * current working directory, as in the reference (src/Mesh.hs:218-221). */
+typedef struct rayhs_render_desc rayhs_render_desc;
+int rayhs_render_desc_load(const char *json_path, rayhs_render_desc **out);
+/* same, from a JSON string */
+int rayhs_render_desc_parse(const char *json_text, rayhs_render_desc **out);
+void rayhs_render_desc_free(rayhs_render_desc *rd);
+const rayhs_scene_desc *rayhs_render_desc_scene(const rayhs_render_desc *rd);
+const rayhs_camera *rayhs_render_desc_camera(const rayhs_render_desc *rd);
+int rayhs_render_desc_width(const rayhs_render_desc *rd);
+int rayhs_render_desc_height(const rayhs_render_desc *rd);
+int rayhs_render_desc_max_depth(const rayhs_render_desc *rd);
+/* deepest tree level over all meshes (root = 0), -1 if there are none */
+int rayhs_render_desc_tree_depth(const rayhs_render_desc *rd);
+
+/* writePPM (src/Image.hs:60-75): ASCII P3, "r g b" + two spaces per pixel, rows
+ * joined by '\n', no trailing newline.  `q` holds toIntC values (RAYHS_OUT_I16). */
+int rayhs_write_ppm_i16(const char *path, int width, int height, const int16_t *q);
+/* same from fp64 colours, quantised with toIntC on the host */
+int rayhs_write_ppm_f64(const char *path, int width, int height, const double *rgb);
+
+/* the build-defined sampler: u(seed, pixel, sample, dim) in [0,1) */
+double rayhs_sample01(uint64_t seed, uint64_t pixel, uint32_t sample, uint32_t dim, uint32_t spp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYHS_H */

@@ -106,6 +106,7 @@ def lib():
         L.orc_sample01.restype = C.c_double
         L.orc_sample01.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_to_int_c.argtypes = [C.c_double]
+        L.orc_set_shadow_exhaustive.argtypes = [C.c_int]
         L.orc_write_ppm.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
         _LIB = L
     return _LIB

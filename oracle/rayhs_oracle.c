@@ -324,18 +324,27 @@ static int closest_intersection(ctx *cx, const orc_scene *s, ray r, hit *out, in
     return have;
 }
 
+/* Counting mode for shadow queries.  0 (default): lazy, as the reference runs
+ * -- stop at the first occluding object in scene order.  1: evaluate every
+ * object (same answer, more work counted); matches the HIP kernel's
+ * RAYHS_FLAG_EXHAUSTIVE run so that work counters can be compared exactly. */
+static int g_shadow_exhaustive = 0;
+void orc_set_shadow_exhaustive(int on) { g_shadow_exhaustive = on; }
+
 /* RayHs.hs:74-87: does any object yield an occluder? Lazy evaluation in the
  * reference stops at the first one (only Just/Nothing is inspected, :94-96). */
 static int shadow_intersection(ctx *cx, const orc_scene *s, const light *l, ray r) {
     hit h;
+    int any = 0;
     for (int i = 0; i < s->nobjs; i++) {
         if (!inter_object(cx, r, &s->objs[i], &h, 0)) continue;
         int in_front = (l->kind == LIGHT_DIRECTIONAL) ? 1 : (vsqrdist(r.o, l->v) > vsqrdist(r.o, h.p));
         if (!in_front) continue;
         if (s->objs[i].mat.kind == ORC_MAT_EMMIT) continue;
-        return 1;
+        if (!g_shadow_exhaustive) return 1;
+        any = 1;
     }
-    return 0;
+    return any;
 }
 
 /* ------------------------------------------------------ Material / ColorMap */

@@ -107,6 +107,10 @@ int orc_render(const orc_scene *s, const orc_camera *cam, int w, int h, int max_
                int spp, uint64_t seed, int row0, int row1, double *rgb_out,
                orc_stats *stats_or_null, int nthreads);
 
+/* 1: shadow queries test every object (work-counter comparison with the
+ * kernel's exhaustive mode); 0: stop at the first occluder like the reference. */
+void orc_set_shadow_exhaustive(int on);
+
 /* probes for unit tests */
 void orc_ray_from_pixel(const orc_camera *cam, double w, double h, double px, double py,
                         double origin[3], double dir[3]);

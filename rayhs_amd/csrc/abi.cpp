@@ -1,0 +1,481 @@
+// abi.cpp -- implementation of the C ABI declared in include/rayhs.h:
+// scene upload into HBM, kernel launch, host-prep wrappers.  No CPU fallback:
+// every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rayhs.h"
+#include "device_scene.h"
+#include "host_scene.hpp"
+
+namespace rayhs {
+hipError_t launch_trace_fast(int variant, int grid, size_t lds_bytes, hipStream_t stream, const DScene &sc, const DCamera &cam,
+                             const DParams &prm, void *out, unsigned long long *counters, unsigned int *ticket, double *frames);
+hipError_t launch_trace_exact(int variant, int grid, size_t lds_bytes, hipStream_t stream, const DScene &sc, const DCamera &cam,
+                              const DParams &prm, void *out, unsigned long long *counters, unsigned int *ticket, double *frames);
+int occupancy_trace_fast(int variant, size_t lds_bytes);
+int occupancy_trace_exact(int variant, size_t lds_bytes);
+}  // namespace rayhs
+
+using namespace rayhs;
+
+static thread_local std::string g_error;
+static int set_error(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return set_error(RAYHS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static constexpr int kTicketSlots = 64;
+
+struct rayhs_scene {
+    int device = 0;
+    int cu_count = 0;
+    DScene d{};
+    std::vector<void *> allocs;
+    int tree_depth = -1;  // deepest level over all meshes
+    // launch workspace (grow-only; steady-state renders allocate nothing)
+    mutable double *frames = nullptr;
+    mutable size_t frames_bytes = 0;
+    mutable unsigned int *tickets = nullptr;
+    mutable unsigned next_ticket = 0;
+    mutable unsigned long long *counters = nullptr;
+    mutable int grid_cache[2][3][2] = {{{0}}};  // [exact][variant] -> {lds_bytes, blocks per CU}
+};
+
+extern "C" const char *rayhs_last_error(void) { return g_error.c_str(); }
+extern "C" int rayhs_abi_version(void) { return RAYHS_ABI_VERSION; }
+extern "C" int rayhs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------- validation
+static int check_desc(const rayhs_scene_desc *d, int &tree_depth) {
+    if (!d) return set_error(RAYHS_ERR_INVALID, "scene description is NULL");
+    if (d->n_objects < 0 || d->n_planes < 0 || d->n_spheres < 0 || d->n_meshes < 0 || d->n_nodes < 0 || d->n_tris < 0 || d->n_lights < 0)
+        return set_error(RAYHS_ERR_INVALID, "negative count in scene description");
+    for (int i = 0; i < d->n_objects; i++) {
+        int k = d->obj_geom_kind[i], g = d->obj_geom_index[i];
+        int lim = k == RAYHS_GEOM_PLANE ? d->n_planes : k == RAYHS_GEOM_SPHERE ? d->n_spheres : k == RAYHS_GEOM_MESH ? d->n_meshes : -1;
+        if (lim < 0 || g < 0 || g >= lim) return set_error(RAYHS_ERR_INVALID, "object %d: bad geometry kind/index (%d, %d)", i, k, g);
+        if (d->mat_kind[i] < 0 || d->mat_kind[i] > RAYHS_MAT_SHOWUV) return set_error(RAYHS_ERR_INVALID, "object %d: bad material kind", i);
+        if (d->cmap_kind[i] < 0 || d->cmap_kind[i] > RAYHS_CMAP_TEXTURE) return set_error(RAYHS_ERR_INVALID, "object %d: bad colour map kind", i);
+        if (d->cmap_kind[i] == RAYHS_CMAP_TEXTURE && (d->mat_kind[i] == RAYHS_MAT_DIFFUSE || d->mat_kind[i] == RAYHS_MAT_PLASTIC)) {
+            int64_t n = (int64_t)d->tex_w[i] * d->tex_h[i];
+            if (d->tex_w[i] <= 0 || d->tex_h[i] <= 0 || d->tex_offset[i] < 0 || d->tex_offset[i] + n > d->n_texels)
+                return set_error(RAYHS_ERR_INVALID, "object %d: texture outside the texel array", i);
+        }
+    }
+    // trees: indices in range, every node reachable at most once (no cycles), depth measured
+    std::vector<int> depth((size_t)d->n_nodes, -1);
+    tree_depth = -1;
+    for (int m = 0; m < d->n_meshes; m++) {
+        int root = d->mesh_root[m];
+        if (root == -1) continue;
+        if (root < 0 || root >= d->n_nodes) return set_error(RAYHS_ERR_INVALID, "mesh %d: root out of range", m);
+        std::vector<int> todo{root};
+        if (depth[(size_t)root] >= 0) return set_error(RAYHS_ERR_INVALID, "mesh %d: root shared with another tree", m);
+        depth[(size_t)root] = 0;
+        while (!todo.empty()) {
+            int k = todo.back();
+            todo.pop_back();
+            tree_depth = std::max(tree_depth, depth[(size_t)k]);
+            if (d->node_tri_count[k] >= 0) {
+                if (d->node_first_tri[k] < 0 || (int64_t)d->node_first_tri[k] + d->node_tri_count[k] > d->n_tris)
+                    return set_error(RAYHS_ERR_INVALID, "node %d: triangle range out of bounds", k);
+                continue;
+            }
+            if (d->node_axis[k] < 0 || d->node_axis[k] > 2) return set_error(RAYHS_ERR_INVALID, "node %d: bad split axis", k);
+            for (int c : {d->node_left[k], d->node_right[k]}) {
+                if (c == -1) continue;
+                if (c < 0 || c >= d->n_nodes) return set_error(RAYHS_ERR_INVALID, "node %d: child out of range", k);
+                if (depth[(size_t)c] >= 0) return set_error(RAYHS_ERR_INVALID, "node %d: child %d reached twice", k, c);
+                depth[(size_t)c] = depth[(size_t)k] + 1;
+                todo.push_back(c);
+            }
+        }
+    }
+    for (int i = 0; i < d->n_lights; i++)
+        if (d->light_kind[i] != RAYHS_LIGHT_DIRECTIONAL && d->light_kind[i] != RAYHS_LIGHT_POINT)
+            return set_error(RAYHS_ERR_INVALID, "light %d: bad kind", i);
+    return RAYHS_OK;
+}
+
+template <class T>
+static int upload(rayhs_scene *s, const std::vector<T> &v, const T **out) {
+    *out = nullptr;
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    s->allocs.push_back(p);
+    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T *)p;
+    return RAYHS_OK;
+}
+
+static double r0(double n1, double n2) { double q = (n1 - n2) / (n1 + n2); return q * q; }  // src/Material.hs:22-24
+
+extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayhs_scene **out) {
+    if (!out) return set_error(RAYHS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int tree_depth = -1;
+    int rc = check_desc(desc, tree_depth);
+    if (rc) return rc;
+    int ndev = rayhs_device_count();
+    if (ndev <= 0) return set_error(RAYHS_ERR_NO_DEVICE, "no HIP device available (librayhs_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return set_error(RAYHS_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+
+    // pack the SoA description into the device records of device_scene.h
+    const rayhs_scene_desc &d = *desc;
+    std::vector<DNode> nodes((size_t)d.n_nodes);
+    for (int k = 0; k < d.n_nodes; k++) {
+        DNode &n = nodes[(size_t)k];
+        for (int c = 0; c < 3; c++) { n.lo[c] = d.node_lo[3 * k + c]; n.hi[c] = d.node_hi[3 * k + c]; }
+        if (d.node_tri_count[k] >= 0) { n.a = d.node_first_tri[k]; n.b = d.node_tri_count[k]; n.flags = DNODE_LEAF; }
+        else { n.a = d.node_left[k]; n.b = d.node_right[k]; n.flags = d.node_axis[k] & 3; }
+        n.pad = 0;
+    }
+    std::vector<DTri> tris((size_t)d.n_tris);
+    std::vector<DTriAttr> attrs((size_t)d.n_tris);
+    for (int k = 0; k < d.n_tris; k++) {
+        const double *p = d.tri_pos + 9 * (size_t)k;
+        DTri &t = tris[(size_t)k];
+        for (int c = 0; c < 3; c++) {
+            t.p0[c] = p[c];
+            t.e1[c] = p[3 + c] - p[c];  // e1 = p1 - p0, e2 = p2 - p0 (src/Mesh.hs:65-66)
+            t.e2[c] = p[6 + c] - p[c];
+        }
+        t.pad = 0;
+        DTriAttr &a = attrs[(size_t)k];
+        const double *n = d.tri_nrm + 9 * (size_t)k, *uv = d.tri_uv + 6 * (size_t)k;
+        for (int c = 0; c < 3; c++) { a.n0[c] = n[c]; a.n1[c] = n[3 + c]; a.n2[c] = n[6 + c]; }
+        for (int c = 0; c < 2; c++) { a.uv0[c] = uv[c]; a.uv1[c] = uv[2 + c]; a.uv2[c] = uv[4 + c]; }
+        a.pad = 0;
+    }
+    std::vector<DPlane> planes((size_t)d.n_planes);
+    std::vector<DSphere> spheres((size_t)d.n_spheres);
+    std::vector<DMesh> meshes((size_t)d.n_meshes);
+    std::vector<DObject> objects((size_t)d.n_objects);
+    std::vector<char> plane_used((size_t)d.n_planes, 0), sphere_used((size_t)d.n_spheres, 0), mesh_used((size_t)d.n_meshes, 0);
+    for (int i = 0; i < d.n_objects; i++) {
+        DObject &o = objects[(size_t)i];
+        std::memset(&o, 0, sizeof o);
+        o.mat_kind = d.mat_kind[i];
+        o.cmap_kind = d.cmap_kind[i];
+        o.tex_w = d.tex_w ? d.tex_w[i] : 0;
+        o.tex_h = d.tex_h ? d.tex_h[i] : 0;
+        o.tex_off = d.tex_offset ? d.tex_offset[i] : 0;
+        o.ior = d.mat_ior[i];
+        o.fr = r0(1.0, o.ior);
+        o.one_m_r0 = 1 - r0(o.ior, 1.0);
+        for (int c = 0; c < 3; c++) { o.ce[c] = d.mat_ce[3 * i + c]; o.c1[c] = d.cmap_c1[3 * i + c]; o.c2[c] = d.cmap_c2[3 * i + c]; }
+        o.size = d.cmap_size[i];
+        const int occl = d.mat_kind[i] != RAYHS_MAT_EMMIT;  // isOccluder (src/RayHs.hs:81-82)
+        const int g = d.obj_geom_index[i];
+        if (d.obj_geom_kind[i] == RAYHS_GEOM_PLANE) {
+            if (plane_used[(size_t)g]++) return set_error(RAYHS_ERR_INVALID, "plane %d referenced by two objects", g);
+            DPlane &p = planes[(size_t)g];
+            for (int c = 0; c < 3; c++) { p.p[c] = d.plane_point[3 * g + c]; p.n[c] = d.plane_normal[3 * g + c]; p.t[c] = d.plane_tangent[3 * g + c]; }
+            // b = cross t n (src/Geometry.hs:76)
+            p.b[0] = p.t[1] * p.n[2] - p.t[2] * p.n[1];
+            p.b[1] = p.t[2] * p.n[0] - p.t[0] * p.n[2];
+            p.b[2] = p.t[0] * p.n[1] - p.t[1] * p.n[0];
+            p.obj = i; p.occluder = occl;
+        } else if (d.obj_geom_kind[i] == RAYHS_GEOM_SPHERE) {
+            if (sphere_used[(size_t)g]++) return set_error(RAYHS_ERR_INVALID, "sphere %d referenced by two objects", g);
+            DSphere &s = spheres[(size_t)g];
+            for (int c = 0; c < 3; c++) s.c[c] = d.sphere_center[3 * g + c];
+            s.r2 = d.sphere_radius[g] * d.sphere_radius[g];  // r ^ 2 (src/Geometry.hs:89)
+            s.obj = i; s.occluder = occl;
+        } else {
+            if (mesh_used[(size_t)g]++) return set_error(RAYHS_ERR_INVALID, "mesh %d referenced by two objects", g);
+            DMesh &m = meshes[(size_t)g];
+            m.root = d.mesh_root[g]; m.obj = i; m.occluder = occl; m.pad = 0;
+        }
+    }
+    // geometry not referenced by any object is dropped from the query loops
+    {
+        std::vector<DPlane> p2; std::vector<DSphere> s2; std::vector<DMesh> m2;
+        for (int g = 0; g < d.n_planes; g++) if (plane_used[(size_t)g]) p2.push_back(planes[(size_t)g]);
+        for (int g = 0; g < d.n_spheres; g++) if (sphere_used[(size_t)g]) s2.push_back(spheres[(size_t)g]);
+        for (int g = 0; g < d.n_meshes; g++) if (mesh_used[(size_t)g]) m2.push_back(meshes[(size_t)g]);
+        planes.swap(p2); spheres.swap(s2); meshes.swap(m2);
+    }
+    std::vector<DLight> lights((size_t)d.n_lights);
+    for (int i = 0; i < d.n_lights; i++) {
+        DLight &l = lights[(size_t)i];
+        l.kind = d.light_kind[i]; l.pad = 0;
+        for (int c = 0; c < 3; c++) { l.v[c] = d.light_vec[3 * i + c]; l.c[c] = d.light_color[3 * i + c]; }
+        l.radius = d.light_radius[i];
+    }
+    std::vector<double> texels;
+    if (d.n_texels > 0) texels.assign(d.texels, d.texels + 3 * (size_t)d.n_texels);
+
+    rayhs_scene *s = new rayhs_scene();
+    s->device = device;
+    s->cu_count = prop.multiProcessorCount;
+    s->tree_depth = tree_depth;
+    auto fail = [&](int code) { rayhs_scene_destroy(s); return code; };
+    if ((rc = upload(s, nodes, &s->d.nodes))) return fail(rc);
+    if ((rc = upload(s, tris, &s->d.tris))) return fail(rc);
+    if ((rc = upload(s, attrs, &s->d.attrs))) return fail(rc);
+    if ((rc = upload(s, planes, &s->d.planes))) return fail(rc);
+    if ((rc = upload(s, spheres, &s->d.spheres))) return fail(rc);
+    if ((rc = upload(s, meshes, &s->d.meshes))) return fail(rc);
+    if ((rc = upload(s, objects, &s->d.objects))) return fail(rc);
+    if ((rc = upload(s, lights, &s->d.lights))) return fail(rc);
+    if ((rc = upload(s, texels, &s->d.texels))) return fail(rc);
+    s->d.n_planes = (int)planes.size();
+    s->d.n_spheres = (int)spheres.size();
+    s->d.n_meshes = (int)meshes.size();
+    s->d.n_objects = d.n_objects;
+    s->d.n_lights = d.n_lights;
+    s->d.n_nodes = d.n_nodes;
+    s->d.n_tris = d.n_tris;
+    void *p = nullptr;
+    if (hipMalloc(&p, sizeof(unsigned int) * kTicketSlots) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(tickets) failed"));
+    s->tickets = (unsigned int *)p;
+    if (hipMalloc(&p, sizeof(unsigned long long) * CNT_SLOTS) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(counters) failed"));
+    s->counters = (unsigned long long *)p;
+    *out = s;
+    return RAYHS_OK;
+}
+
+extern "C" void rayhs_scene_destroy(rayhs_scene *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    for (void *p : s->allocs) (void)hipFree(p);
+    if (s->frames) (void)hipFree(s->frames);
+    if (s->tickets) (void)hipFree(s->tickets);
+    if (s->counters) (void)hipFree(s->counters);
+    delete s;
+}
+
+// -------------------------------------------------------------------- render
+extern "C" int rayhs_render_rows(const rayhs_render_params *p) {
+    if (!p || p->row0 < 0 || p->row1 < p->row0 || p->stripe_count < 1 || p->stripe_rows < 1 || p->stripe_rank < 0 || p->stripe_rank >= p->stripe_count)
+        return set_error(RAYHS_ERR_INVALID, "bad row/stripe selection");
+    int total = p->row1 - p->row0, n = 0;
+    int stripes = (total + p->stripe_rows - 1) / p->stripe_rows;
+    for (int s = p->stripe_rank; s < stripes; s += p->stripe_count) n += std::min(p->stripe_rows, total - s * p->stripe_rows);
+    return n;
+}
+
+// rayFromPixel's per-call constants (src/Projection.hs:22-46, src/Mat.hs:89-93)
+static void make_camera(const rayhs_camera &c, int width, int height, DCamera &o) {
+    std::memset(&o, 0, sizeof o);
+    auto norm = [](const double v[3], double out[3]) {
+        double l = 1 / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        out[0] = l * v[0]; out[1] = l * v[1]; out[2] = l * v[2];
+    };
+    auto crs = [](const double a[3], const double b[3], double out[3]) {
+        out[0] = a[1] * b[2] - a[2] * b[1]; out[1] = a[2] * b[0] - a[0] * b[2]; out[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    double diff[3] = {c.target[0] - c.position[0], c.target[1] - c.position[1], c.target[2] - c.position[2]};
+    double fwd[3], right[3], up[3], tmp[3];
+    norm(diff, fwd);
+    crs(c.up, fwd, tmp);
+    norm(tmp, right);
+    crs(fwd, right, up);
+    // fromColumns right up forward
+    o.m[0] = right[0]; o.m[1] = up[0]; o.m[2] = fwd[0];
+    o.m[3] = right[1]; o.m[4] = up[1]; o.m[5] = fwd[1];
+    o.m[6] = right[2]; o.m[7] = up[2]; o.m[8] = fwd[2];
+    for (int k = 0; k < 3; k++) o.pos[k] = c.position[k];
+    o.w = (double)width; o.h = (double)height;
+    o.half_w = o.w / 2; o.half_h = o.h / 2;
+    double aspect = o.w / o.h;  // aspectSize (src/Projection.hs:41-46)
+    if (aspect > 1) { o.apw = o.w; o.aph = o.w / aspect; } else { o.apw = aspect * o.h; o.aph = o.h; }
+    o.f = 0.5 * o.h / (std::tan(0.5) * c.fovy);  // sic: (tan 0.5) * fovy (src/Projection.hs:35)
+    o.proj_kind = c.proj_kind;
+}
+
+static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_render_params *p, DCamera &dc, DParams &dp,
+                          int &variant, bool &exact, int &grid, size_t &lds) {
+    if (!s || !cam || !p) return set_error(RAYHS_ERR_INVALID, "NULL argument");
+    if (p->width <= 0 || p->height <= 0 || p->max_depth < 0 || p->spp < 1) return set_error(RAYHS_ERR_INVALID, "bad width/height/maxDepth/spp");
+    if (p->row1 > p->height) return set_error(RAYHS_ERR_INVALID, "row1 beyond the image");
+    if (p->out_format < RAYHS_OUT_F32 || p->out_format > RAYHS_OUT_I16) return set_error(RAYHS_ERR_INVALID, "bad out_format");
+    if (cam->proj_kind != RAYHS_PROJ_ORTHOGRAPHIC && cam->proj_kind != RAYHS_PROJ_PERSPECTIVE) return set_error(RAYHS_ERR_INVALID, "bad projection kind");
+    int rows = rayhs_render_rows(p);
+    if (rows < 0) return rows;
+    if ((p->flags & RAYHS_FLAG_EXHAUSTIVE) && !(p->flags & RAYHS_FLAG_COUNT)) return set_error(RAYHS_ERR_INVALID, "RAYHS_FLAG_EXHAUSTIVE needs RAYHS_FLAG_COUNT");
+    make_camera(*cam, p->width, p->height, dc);
+    std::memset(&dp, 0, sizeof dp);
+    dp.width = p->width; dp.height = p->height; dp.max_depth = p->max_depth; dp.spp = p->spp; dp.seed = p->seed;
+    dp.row0 = p->row0; dp.n_rows = rows;
+    dp.stripe_rows = p->stripe_rows; dp.stripe_rank = p->stripe_rank; dp.stripe_count = p->stripe_count;
+    dp.out_format = p->out_format;
+    dp.tiles_x = (p->width + 7) / 8;
+    dp.n_tiles = dp.tiles_x * ((rows + 7) / 8);
+    dp.stack_cap = std::max(s->tree_depth + 2, 4);
+    exact = (p->flags & RAYHS_FLAG_EXACT) != 0;
+    variant = (p->flags & RAYHS_FLAG_EXHAUSTIVE) ? 2 : (p->flags & RAYHS_FLAG_COUNT) ? 1 : 0;
+    lds = (size_t)dp.stack_cap * TRACE_BLOCK * sizeof(int);
+    if (lds > 160 * 1024) return set_error(RAYHS_ERR_UNSUPPORTED, "tree depth %d needs %zu B of LDS stack per workgroup (limit 160 KiB)", s->tree_depth, lds);
+    // persistent grid: as many workgroups as the chip keeps resident
+    int *cache = s->grid_cache[exact ? 1 : 0][variant];
+    if (cache[0] != (int)lds || cache[1] <= 0) {
+        int per_cu = exact ? occupancy_trace_exact(variant, lds) : occupancy_trace_fast(variant, lds);
+        if (per_cu <= 0) return set_error(RAYHS_ERR_HIP, "trace kernel cannot be resident (occupancy query returned %d)", per_cu);
+        cache[0] = (int)lds; cache[1] = per_cu;
+    }
+    int wanted = (dp.n_tiles + 3) / 4;  // 4 waves per workgroup, one tile per wave at a time
+    grid = std::max(1, std::min(wanted, s->cu_count * cache[1]));
+    dp.frame_stride = grid * TRACE_BLOCK;
+    return RAYHS_OK;
+}
+
+static int ensure_workspace(const rayhs_scene *s, const DParams &dp) {
+    size_t need = (size_t)std::max(dp.max_depth, 1) * FRAME_SLOTS * (size_t)dp.frame_stride * sizeof(double);
+    if (need > s->frames_bytes) {
+        if (s->frames) HIP_TRY(hipFree(s->frames));
+        s->frames = nullptr; s->frames_bytes = 0;
+        void *p = nullptr;
+        HIP_TRY(hipMalloc(&p, need));
+        s->frames = (double *)p; s->frames_bytes = need;
+    }
+    return RAYHS_OK;
+}
+
+static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_render_params *p, void *d_out, hipStream_t st,
+                  uint64_t *d_counters, hipEvent_t e0, hipEvent_t e1) {
+    DCamera dc; DParams dp; int variant, grid; bool exact; size_t lds;
+    int rc = prepare_launch(s, cam, p, dc, dp, variant, exact, grid, lds);
+    if (rc) return rc;
+    if (!d_out) return set_error(RAYHS_ERR_INVALID, "d_out is NULL");
+    if (variant != 0 && !d_counters) return set_error(RAYHS_ERR_INVALID, "RAYHS_FLAG_COUNT needs d_counters");
+    if (dp.n_tiles == 0) return RAYHS_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    if ((rc = ensure_workspace(s, dp))) return rc;
+    unsigned int *ticket = s->tickets + (s->next_ticket++ % kTicketSlots);
+    HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned int), st));
+    if (e0) HIP_TRY(hipEventRecord(e0, st));
+    hipError_t e = exact ? launch_trace_exact(variant, grid, lds, st, s->d, dc, dp, d_out, (unsigned long long *)d_counters, ticket, s->frames)
+                         : launch_trace_fast(variant, grid, lds, st, s->d, dc, dp, d_out, (unsigned long long *)d_counters, ticket, s->frames);
+    if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "trace kernel launch failed: %s", hipGetErrorString(e));
+    if (e1) HIP_TRY(hipEventRecord(e1, st));
+    return RAYHS_OK;
+}
+
+extern "C" int rayhs_render_device(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_render_params *p, void *d_out,
+                                   void *hip_stream, uint64_t *d_counters) {
+    return launch(s, cam, p, d_out, (hipStream_t)hip_stream, d_counters, nullptr, nullptr);
+}
+
+extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_render_params *p, void *out_host, rayhs_stats *stats) {
+    if (!s || !p || !out_host) return set_error(RAYHS_ERR_INVALID, "NULL argument");
+    int rows = rayhs_render_rows(p);
+    if (rows < 0) return rows;
+    if (p->width <= 0) return set_error(RAYHS_ERR_INVALID, "bad width");
+    HIP_TRY(hipSetDevice(s->device));
+    size_t esz = p->out_format == RAYHS_OUT_F64 ? 8 : p->out_format == RAYHS_OUT_F32 ? 4 : 2;
+    size_t bytes = (size_t)rows * (size_t)p->width * 3 * esz;
+    void *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_out, std::max<size_t>(bytes, 16)));
+    const bool count = (p->flags & RAYHS_FLAG_COUNT) != 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = RAYHS_OK;
+    hipError_t he = hipSuccess;
+    do {
+        if (count && (he = hipMemset(s->counters, 0, sizeof(unsigned long long) * CNT_SLOTS)) != hipSuccess) break;
+        if ((he = hipEventCreate(&e0)) != hipSuccess || (he = hipEventCreate(&e1)) != hipSuccess) break;
+        rc = launch(s, cam, p, d_out, nullptr, count ? (uint64_t *)s->counters : nullptr, e0, e1);
+        if (rc) break;
+        if ((he = hipDeviceSynchronize()) != hipSuccess) break;
+        if (bytes && (he = hipMemcpy(out_host, d_out, bytes, hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if (stats) {
+            std::memset(stats, 0, sizeof *stats);
+            float ms = 0;
+            if (bytes && (he = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) break;
+            stats->kernel_ms = ms;
+            if (count) {
+                unsigned long long c[CNT_SLOTS];
+                if ((he = hipMemcpy(c, s->counters, sizeof c, hipMemcpyDeviceToHost)) != hipSuccess) break;
+                stats->rays_primary = c[CNT_PRIMARY]; stats->rays_reflect = c[CNT_REFLECT]; stats->rays_refract = c[CNT_REFRACT];
+                stats->rays_refract_exit = c[CNT_REFRACT_EXIT]; stats->rays_shadow = c[CNT_SHADOW];
+                stats->nodes_tested = c[CNT_NODES]; stats->tris_tested = c[CNT_TRIS]; stats->prims_tested = c[CNT_PRIMS];
+                stats->shaded_hits = c[CNT_SHADED]; stats->pixels = c[CNT_PIXELS];
+            }
+        }
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_out);
+    if (rc) return rc;
+    if (he != hipSuccess) return set_error(RAYHS_ERR_HIP, "HIP call failed in rayhs_render: %s", hipGetErrorString(he));
+    return RAYHS_OK;
+}
+
+// ----------------------------------------------------------------- host prep
+struct rayhs_render_desc { std::unique_ptr<RenderDescData> data; };
+
+template <class F>
+static int guarded(F f) {
+    try {
+        return f();
+    } catch (const SceneError &e) {
+        return set_error(e.code, "%s", e.what());
+    } catch (const std::exception &e) {
+        return set_error(RAYHS_ERR_INVALID, "%s", e.what());
+    }
+}
+
+extern "C" int rayhs_render_desc_load(const char *json_path, rayhs_render_desc **out) {
+    if (!json_path || !out) return set_error(RAYHS_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    return guarded([&] { auto d = load_render_desc(json_path); *out = new rayhs_render_desc{std::move(d)}; return (int)RAYHS_OK; });
+}
+extern "C" int rayhs_render_desc_parse(const char *json_text, rayhs_render_desc **out) {
+    if (!json_text || !out) return set_error(RAYHS_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    return guarded([&] { auto d = decode_render_desc(json_text); *out = new rayhs_render_desc{std::move(d)}; return (int)RAYHS_OK; });
+}
+extern "C" void rayhs_render_desc_free(rayhs_render_desc *rd) { delete rd; }
+extern "C" const rayhs_scene_desc *rayhs_render_desc_scene(const rayhs_render_desc *rd) { return rd ? &rd->data->flat.view : nullptr; }
+extern "C" const rayhs_camera *rayhs_render_desc_camera(const rayhs_render_desc *rd) { return rd ? &rd->data->camera : nullptr; }
+extern "C" int rayhs_render_desc_width(const rayhs_render_desc *rd) { return rd ? rd->data->width : 0; }
+extern "C" int rayhs_render_desc_height(const rayhs_render_desc *rd) { return rd ? rd->data->height : 0; }
+extern "C" int rayhs_render_desc_max_depth(const rayhs_render_desc *rd) { return rd ? rd->data->max_depth : 0; }
+extern "C" int rayhs_render_desc_tree_depth(const rayhs_render_desc *rd) { return rd ? rd->data->tree_depth : -1; }
+
+extern "C" int rayhs_write_ppm_i16(const char *path, int w, int h, const int16_t *q) {
+    if (!path || !q || w <= 0 || h <= 0) return set_error(RAYHS_ERR_INVALID, "bad argument");
+    return guarded([&] { write_ppm_i16(path, w, h, q); return (int)RAYHS_OK; });
+}
+extern "C" int rayhs_write_ppm_f64(const char *path, int w, int h, const double *rgb) {
+    if (!path || !rgb || w <= 0 || h <= 0) return set_error(RAYHS_ERR_INVALID, "bad argument");
+    return guarded([&] { write_ppm_f64(path, w, h, rgb); return (int)RAYHS_OK; });
+}
+
+static uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+extern "C" double rayhs_sample01(uint64_t seed, uint64_t pixel, uint32_t sample, uint32_t dim, uint32_t spp) {
+    uint64_t ctr = (pixel * (uint64_t)spp + sample) * 2u + dim;
+    uint64_t x = mix64(ctr + mix64(seed + 0x9e3779b97f4a7c15ULL));
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}

@@ -1,0 +1,103 @@
+// device_scene.h -- HBM-resident scene layout shared by the launcher (abi.cpp)
+// and the trace kernels (trace_kernel.hip).
+//
+// Everything stays fp64 (src/Vec.hs:29-31).  Values the reference recomputes
+// per ray from scene constants (triangle edges, plane bitangent, r*r, Fresnel
+// r0) are computed ONCE on the host with the same fp64 operations, so the
+// stored value is bit-identical to what the reference would derive.
+#pragma once
+#include <stdint.h>
+
+namespace rayhs {
+
+// 64 B, one 64-byte-aligned record per tree node (src/KDTree.hs:59-61).
+struct alignas(16) DNode {
+    double lo[3], hi[3];  // Box (src/KDTree.hs:13-14)
+    int32_t a, b;         // inner: left/right child (-1 = Empty); leaf: first triangle, count
+    int32_t flags;        // bit 31 = leaf, bits 0..1 = split axis of an inner node
+    int32_t pad;
+};
+static constexpr int32_t DNODE_LEAF = (int32_t)0x80000000;
+
+// 80 B: what triangleIntersection reads (src/Mesh.hs:59-72): p0, e1 = p1-p0, e2 = p2-p0.
+struct alignas(16) DTri {
+    double p0[3], e1[3], e2[3];
+    double pad;
+};
+// 128 B: read once per shaded hit (src/Mesh.hs:73-74).
+struct alignas(16) DTriAttr {
+    double n0[3], n1[3], n2[3];
+    double uv0[2], uv1[2], uv2[2];
+    double pad;
+};
+
+struct DPlane {   // src/Geometry.hs:62, 70-79
+    double p[3], n[3], t[3], b[3];  // b = cross t n
+    int32_t obj, occluder;          // scene object index; 0 for Emmit (never an occluder, src/RayHs.hs:81)
+};
+struct DSphere {  // src/Geometry.hs:63, 81-96
+    double c[3], r2;                // r2 = r ^ 2
+    int32_t obj, occluder;
+};
+struct DMesh {
+    int32_t root;                   // -1 = Empty
+    int32_t obj, occluder, pad;
+};
+struct DObject {  // Material (src/Material.hs:13-19) + ColorMap (src/ColorMap.hs:11-16) of one object
+    int32_t mat_kind, cmap_kind, tex_w, tex_h;
+    int64_t tex_off;
+    double ior;
+    double fr;          // r0 1.0 ior  (src/Material.hs:28)
+    double one_m_r0;    // 1 - r0 ior 1.0 (src/RayHs.hs:133)
+    double ce[3], c1[3], c2[3], size;
+};
+struct DLight {   // src/Light.hs:8-10
+    int32_t kind, pad;
+    double v[3], c[3], radius;
+};
+
+struct DScene {
+    const DNode *nodes;
+    const DTri *tris;
+    const DTriAttr *attrs;
+    const DPlane *planes;
+    const DSphere *spheres;
+    const DMesh *meshes;
+    const DObject *objects;
+    const DLight *lights;
+    const double *texels;
+    int32_t n_planes, n_spheres, n_meshes, n_objects, n_lights, n_nodes, n_tris;
+};
+
+// Camera constants of rayFromPixel / unproject / lookAt (src/Projection.hs:22-46,
+// src/Mat.hs:89-93), evaluated on the host once per call (the reference
+// re-evaluates them per pixel to the same values).
+struct DCamera {
+    double pos[3];
+    double m[9];          // lookAt matrix, row-major
+    double w, h;          // fromIntegral width / height
+    double half_w, half_h;  // w/2, h/2
+    double apw, aph;      // aspectSize
+    double f;             // 0.5 * h / (tan 0.5 * fovy)
+    int32_t proj_kind, pad;
+};
+
+struct DParams {
+    int32_t width, height, max_depth, spp;
+    uint64_t seed;
+    int32_t row0, n_rows;             // first candidate row, rows rendered by this call
+    int32_t stripe_rows, stripe_rank, stripe_count;
+    int32_t out_format;
+    int32_t tiles_x, n_tiles;         // 8x8-pixel tiles over (width x n_rows)
+    int32_t stack_cap;                // per-lane LDS stack entries
+    int32_t frame_stride;             // threads in the grid (frame workspace stride)
+};
+
+// counters[] slots
+enum { CNT_PRIMARY = 0, CNT_REFLECT, CNT_REFRACT, CNT_REFRACT_EXIT, CNT_SHADOW, CNT_NODES, CNT_TRIS,
+       CNT_PRIMS, CNT_SHADED, CNT_PIXELS, CNT_SLOTS = 16 };
+
+static constexpr int TRACE_BLOCK = 256;     // threads per workgroup (4 waves)
+static constexpr int FRAME_SLOTS = 14;      // doubles per continuation frame
+
+}  // namespace rayhs

@@ -1,0 +1,18 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+
+
+@pytest.fixture(autouse=True)
+def _repo_cwd(monkeypatch):
+    # scene files name meshes relative to the working directory (src/Mesh.hs:218-221)
+    monkeypatch.chdir(ROOT)
