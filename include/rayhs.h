@@ -123,7 +123,9 @@ typedef struct rayhs_camera {
 enum { RAYHS_OUT_F32 = 0, RAYHS_OUT_F64 = 1, RAYHS_OUT_I16 = 2 };
 
 /* flags */
-#define RAYHS_FLAG_EXACT      1u /* kernels built with -ffp-contract=off: same fp64 operations as the reference */
+#define RAYHS_FLAG_FMA        1u /* use the kernels built with fused multiply-add (~10 % faster).  Default is the
+                                  -ffp-contract=off build, whose fp64 operations are the reference's one for one;
+                                  with FMA last bits differ and exact-tie cases (a ray parallel to a plane) can flip */
 #define RAYHS_FLAG_EXHAUSTIVE 2u /* visit exactly the reference's node set (no ordering, no pruning, no any-hit exit) */
 #define RAYHS_FLAG_COUNT      4u /* instrumented run: fill the work counters of rayhs_stats */
 

@@ -886,7 +886,7 @@ int orc_render(const orc_scene *s, const orc_camera *cam, int w, int h, int max_
     {
         ctx cx; memset(&cx, 0, sizeof cx);
 #ifdef _OPENMP
-#pragma omp for schedule(dynamic, 1)
+#pragma omp for collapse(2) schedule(dynamic, 16)
 #endif
         for (int y = row0; y < row1; y++) {
             for (int x = 0; x < w; x++) {

@@ -329,7 +329,7 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     dp.tiles_x = (p->width + 7) / 8;
     dp.n_tiles = dp.tiles_x * ((rows + 7) / 8);
     dp.stack_cap = std::max(s->tree_depth + 2, 4);
-    exact = (p->flags & RAYHS_FLAG_EXACT) != 0;
+    exact = (p->flags & RAYHS_FLAG_FMA) == 0;
     variant = (p->flags & RAYHS_FLAG_EXHAUSTIVE) ? 2 : (p->flags & RAYHS_FLAG_COUNT) ? 1 : 0;
     lds = (size_t)dp.stack_cap * TRACE_BLOCK * sizeof(int);
     if (lds > 160 * 1024) return set_error(RAYHS_ERR_UNSUPPORTED, "tree depth %d needs %zu B of LDS stack per workgroup (limit 160 KiB)", s->tree_depth, lds);

@@ -15,7 +15,7 @@ CLI_PATH = os.path.join(_HERE, "bin", "rayhs")
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 GEOM_PLANE, GEOM_SPHERE, GEOM_MESH = 0, 1, 2
 OUT_F32, OUT_F64, OUT_I16 = 0, 1, 2
-FLAG_EXACT, FLAG_EXHAUSTIVE, FLAG_COUNT = 1, 2, 4
+FLAG_FMA, FLAG_EXHAUSTIVE, FLAG_COUNT = 1, 2, 4
 
 _pi32 = C.POINTER(C.c_int32)
 _pi64 = C.POINTER(C.c_int64)

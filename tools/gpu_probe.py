@@ -29,15 +29,15 @@ def scene_case(path, w, h, spp=1, mesh=None, depth=None):
     md = jd["maxDepth"] if depth is None else depth
     t = time.time(); oimg, ost = sc.render(cam, w, h, md, spp=spp); tcpu = time.time() - t
     name = f"{path.split('/')[-1]} {w}x{h} spp{spp} mesh={mesh}"
-    for flags, tag in ((L.FLAG_EXACT, "exact"), (0, "fast")):
+    for flags, tag in ((0, "exact"), (L.FLAG_FMA, "fma")):
         g, st = r.ray_trace(spp=spp, flags=flags)
         report(f"{name} [{tag}] kernel {st['kernel_ms']:.2f} ms (oracle {tcpu*1e3:.0f} ms, {len(__import__('os').sched_getaffinity(0))} thr)", g, oimg)
-    g, st = r.ray_trace(spp=spp, flags=L.FLAG_EXACT | L.FLAG_COUNT)
+    g, st = r.ray_trace(spp=spp, flags=L.FLAG_COUNT)
     print("   counted (pruned)   :", {k: v for k, v in st.items() if k != "kernel_ms"}, flush=True)
     O.lib().orc_set_shadow_exhaustive(1)
     _, ost2 = sc.render(cam, w, h, md, spp=spp)
     O.lib().orc_set_shadow_exhaustive(0)
-    g2, st2 = r.ray_trace(spp=spp, flags=L.FLAG_EXACT | L.FLAG_COUNT | L.FLAG_EXHAUSTIVE)
+    g2, st2 = r.ray_trace(spp=spp, flags=L.FLAG_COUNT | L.FLAG_EXHAUSTIVE)
     print("   counted (exhaustive):", {k: v for k, v in st2.items() if k != "kernel_ms"})
     print("   oracle (exhaustive) :", ost2)
     print("   exhaustive image == pruned image:", np.array_equal(g, g2), " counters equal oracle:",
@@ -58,7 +58,7 @@ if __name__ == "__main__":
     json.dump(jd, open("/tmp/_d.json", "w"))
     r = build_rendering("/tmp/_d.json", width=1920, height=1080)
     for spp in (1, 16):
-        for flags, tag in ((0, "fast"), (L.FLAG_EXACT, "exact")):
+        for flags, tag in ((L.FLAG_FMA, "fma"), (0, "exact")):
             for rep in range(2):
                 g, st = r.ray_trace(spp=spp, flags=flags, out_format=L.OUT_F32)
                 print(f"dragon.obj 1080p spp{spp} [{tag}] kernel {st['kernel_ms']:.2f} ms", flush=True)
