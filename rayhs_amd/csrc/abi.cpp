@@ -6,11 +6,13 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/rayhs.h"
+#include "bvh_build.hpp"
 #include "device_scene.h"
 #include "host_scene.hpp"
 
@@ -21,6 +23,8 @@ hipError_t launch_trace_exact(int variant, int grid, size_t lds_bytes, hipStream
                               const DParams &prm, void *out, unsigned long long *counters, unsigned int *ticket, double *frames);
 int occupancy_trace_fast(int variant, size_t lds_bytes);
 int occupancy_trace_exact(int variant, size_t lds_bytes);
+int stack_entry_bytes_fast(int variant);
+int stack_entry_bytes_exact(int variant);
 }  // namespace rayhs
 
 using namespace rayhs;
@@ -48,14 +52,15 @@ struct rayhs_scene {
     int cu_count = 0;
     DScene d{};
     std::vector<void *> allocs;
-    int tree_depth = -1;  // deepest level over all meshes
+    int tree_depth = -1;  // deepest level of the reference trees over all meshes
+    int fast_depth = 0;   // deepest inner node of the fast BVHs
     // launch workspace (grow-only; steady-state renders allocate nothing)
     mutable double *frames = nullptr;
     mutable size_t frames_bytes = 0;
     mutable unsigned int *tickets = nullptr;
     mutable unsigned next_ticket = 0;
     mutable unsigned long long *counters = nullptr;
-    mutable int grid_cache[2][3][2] = {{{0}}};  // [exact][variant] -> {lds_bytes, blocks per CU}
+    mutable int grid_cache[2][4][2] = {{{0}}};  // [exact][variant] -> {lds_bytes, blocks per CU}
 };
 
 extern "C" const char *rayhs_last_error(void) { return g_error.c_str(); }
@@ -155,22 +160,85 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
         else { n.a = d.node_left[k]; n.b = d.node_right[k]; n.flags = d.node_axis[k] & 3; }
         n.pad = 0;
     }
-    std::vector<DTri> tris((size_t)d.n_tris);
-    std::vector<DTriAttr> attrs((size_t)d.n_tris);
-    for (int k = 0; k < d.n_tris; k++) {
+    auto pack_tri = [&](int k, DTri &t, DTriAttr &a) {
         const double *p = d.tri_pos + 9 * (size_t)k;
-        DTri &t = tris[(size_t)k];
         for (int c = 0; c < 3; c++) {
             t.p0[c] = p[c];
             t.e1[c] = p[3 + c] - p[c];  // e1 = p1 - p0, e2 = p2 - p0 (src/Mesh.hs:65-66)
             t.e2[c] = p[6 + c] - p[c];
         }
-        t.pad = 0;
-        DTriAttr &a = attrs[(size_t)k];
         const double *n = d.tri_nrm + 9 * (size_t)k, *uv = d.tri_uv + 6 * (size_t)k;
         for (int c = 0; c < 3; c++) { a.n0[c] = n[c]; a.n1[c] = n[3 + c]; a.n2[c] = n[6 + c]; }
         for (int c = 0; c < 2; c++) { a.uv0[c] = uv[c]; a.uv1[c] = uv[2 + c]; a.uv2[c] = uv[4 + c]; }
         a.pad = 0;
+    };
+    std::vector<DTri> tris((size_t)d.n_tris);
+    std::vector<DTriAttr> attrs((size_t)d.n_tris);
+    for (int k = 0; k < d.n_tris; k++) {
+        pack_tri(k, tris[(size_t)k], attrs[(size_t)k]);
+        tris[(size_t)k].rank = k; tris[(size_t)k].leaf_first = k;  // overwritten for triangles reachable from a tree
+    }
+    // per mesh: the reference's left-to-right leaf order gives every triangle its rank (exact-t ties are
+    // resolved by it), then the fast BVH is built over the same triangles and they are re-ordered into its leaves
+    std::vector<FNode> fnodes;
+    std::vector<DTri> ftris;
+    std::vector<DTriAttr> fattrs;
+    std::vector<int> mesh_froot((size_t)d.n_meshes, FNODE_NONE), mesh_tri_base((size_t)d.n_meshes, 0);
+    std::vector<double> mesh_center(3 * (size_t)d.n_meshes, 0.0);
+    std::vector<float> mesh_fbox(6 * (size_t)d.n_meshes, 0.0f);
+    int fast_depth = 0;
+    for (int m = 0; m < d.n_meshes; m++) {
+        std::vector<int> ids;       // triangle indices in reference DFS order
+        std::vector<int> todo;
+        if (d.mesh_root[m] >= 0) todo.push_back(d.mesh_root[m]);
+        while (!todo.empty()) {
+            int k = todo.back();
+            todo.pop_back();
+            if (d.node_tri_count[k] >= 0) {
+                int first_rank = (int)ids.size();
+                for (int i = 0; i < d.node_tri_count[k]; i++) {
+                    int t = d.node_first_tri[k] + i;
+                    tris[(size_t)t].rank = (int)ids.size();
+                    tris[(size_t)t].leaf_first = first_rank;
+                    ids.push_back(t);
+                }
+            } else {
+                if (d.node_right[k] >= 0) todo.push_back(d.node_right[k]);
+                if (d.node_left[k] >= 0) todo.push_back(d.node_left[k]);
+            }
+        }
+        FastBvh bvh;
+        build_fast_bvh(d.tri_pos, ids, bvh);
+        fast_depth = std::max(fast_depth, bvh.depth);
+        const int node_base = (int)fnodes.size(), tri_base = (int)ftris.size();
+        mesh_tri_base[(size_t)m] = tri_base;
+        double ext = 0, ctr[3];
+        for (int c = 0; c < 3; c++) { ctr[c] = 0.5 * (bvh.lo[c] + bvh.hi[c]); ext = std::max(ext, bvh.hi[c] - bvh.lo[c]); mesh_center[3 * (size_t)m + (size_t)c] = ctr[c]; }
+        // boxes are stored relative to the mesh centre, rounded outward and inflated by 2^-18 of the mesh
+        // extent: 64x the fp32 rounding error of a ray origin inside the mesh bounds (trace_kernel.hip)
+        const double infl = std::max(ext, 1e-300) * (1.0 / 262144.0);
+        auto quant = [&](const double *lo, const double *hi, float *flo, float *fhi) {
+            for (int c = 0; c < 3; c++) {
+                if (lo[c] <= hi[c]) { flo[c] = round_down_f32((lo[c] - ctr[c]) - infl); fhi[c] = round_up_f32((hi[c] - ctr[c]) + infl); }
+                else { flo[c] = INFINITY; fhi[c] = -INFINITY; }
+            }
+        };
+        quant(bvh.lo, bvh.hi, &mesh_fbox[6 * (size_t)m], &mesh_fbox[6 * (size_t)m + 3]);
+        auto child = [&](int c) { return c == FNODE_NONE ? FNODE_NONE : c >= 0 ? c + node_base : c; };
+        for (const FNodeBuild &nb : bvh.nodes) {
+            FNode fn;
+            std::memset(&fn, 0, sizeof fn);
+            quant(nb.lo0, nb.hi0, fn.lo0, fn.hi0);
+            quant(nb.lo1, nb.hi1, fn.lo1, fn.hi1);
+            fn.c0 = child(nb.c0); fn.c1 = child(nb.c1);
+            fnodes.push_back(fn);
+        }
+        if (bvh.root != FNODE_NONE) mesh_froot[(size_t)m] = bvh.root + node_base;
+        for (int pos : bvh.order) {
+            int t = ids[(size_t)pos];
+            ftris.push_back(tris[(size_t)t]);
+            fattrs.push_back(attrs[(size_t)t]);
+        }
     }
     std::vector<DPlane> planes((size_t)d.n_planes);
     std::vector<DSphere> spheres((size_t)d.n_spheres);
@@ -210,7 +278,17 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
         } else {
             if (mesh_used[(size_t)g]++) return set_error(RAYHS_ERR_INVALID, "mesh %d referenced by two objects", g);
             DMesh &m = meshes[(size_t)g];
-            m.root = d.mesh_root[g]; m.obj = i; m.occluder = occl; m.pad = 0;
+            std::memset(&m, 0, sizeof m);
+            m.root = d.mesh_root[g]; m.obj = i; m.occluder = occl;
+            m.froot = mesh_froot[(size_t)g]; m.tri_base = mesh_tri_base[(size_t)g];
+            for (int c = 0; c < 3; c++) {
+                // the reference root's own box (src/KDTree.hs:84); an Empty tree is never entered
+                m.lo[c] = m.root >= 0 ? d.node_lo[3 * m.root + c] : 0;
+                m.hi[c] = m.root >= 0 ? d.node_hi[3 * m.root + c] : 0;
+                m.center[c] = mesh_center[3 * (size_t)g + (size_t)c];
+                m.flo[c] = mesh_fbox[6 * (size_t)g + (size_t)c];
+                m.fhi[c] = mesh_fbox[6 * (size_t)g + 3 + (size_t)c];
+            }
         }
     }
     // geometry not referenced by any object is dropped from the query loops
@@ -235,10 +313,14 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
     s->device = device;
     s->cu_count = prop.multiProcessorCount;
     s->tree_depth = tree_depth;
+    s->fast_depth = fast_depth;
     auto fail = [&](int code) { rayhs_scene_destroy(s); return code; };
     if ((rc = upload(s, nodes, &s->d.nodes))) return fail(rc);
     if ((rc = upload(s, tris, &s->d.tris))) return fail(rc);
     if ((rc = upload(s, attrs, &s->d.attrs))) return fail(rc);
+    if ((rc = upload(s, fnodes, &s->d.fnodes))) return fail(rc);
+    if ((rc = upload(s, ftris, &s->d.ftris))) return fail(rc);
+    if ((rc = upload(s, fattrs, &s->d.fattrs))) return fail(rc);
     if ((rc = upload(s, planes, &s->d.planes))) return fail(rc);
     if ((rc = upload(s, spheres, &s->d.spheres))) return fail(rc);
     if ((rc = upload(s, meshes, &s->d.meshes))) return fail(rc);
@@ -252,6 +334,7 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
     s->d.n_lights = d.n_lights;
     s->d.n_nodes = d.n_nodes;
     s->d.n_tris = d.n_tris;
+    s->d.n_fnodes = (int)fnodes.size();
     void *p = nullptr;
     if (hipMalloc(&p, sizeof(unsigned int) * kTicketSlots) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(tickets) failed"));
     s->tickets = (unsigned int *)p;
@@ -328,16 +411,20 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     dp.out_format = p->out_format;
     dp.tiles_x = (p->width + 7) / 8;
     dp.n_tiles = dp.tiles_x * ((rows + 7) / 8);
-    dp.stack_cap = std::max(s->tree_depth + 2, 4);
     exact = (p->flags & RAYHS_FLAG_FMA) == 0;
-    variant = (p->flags & RAYHS_FLAG_EXHAUSTIVE) ? 2 : (p->flags & RAYHS_FLAG_COUNT) ? 1 : 0;
-    lds = (size_t)dp.stack_cap * TRACE_BLOCK * sizeof(int);
-    if (lds > 160 * 1024) return set_error(RAYHS_ERR_UNSUPPORTED, "tree depth %d needs %zu B of LDS stack per workgroup (limit 160 KiB)", s->tree_depth, lds);
+    // kernel variants: 0 fast (16-bit stack entries, < 65536 BVH nodes), 3 fast (32-bit entries),
+    // 1 counting, 2 exhaustive + counting (the reference's tree)
+    variant = (p->flags & RAYHS_FLAG_EXHAUSTIVE) ? 2 : (p->flags & RAYHS_FLAG_COUNT) ? 1 : (s->d.n_fnodes < 65536 && s->d.n_nodes < 65536 ? 0 : 3);
+    dp.stack_cap = std::max(std::max(s->tree_depth, s->fast_depth) + 2, 4);  // either tree may be walked (trace_kernel.hip)
+    const int entry = exact ? stack_entry_bytes_exact(variant) : stack_entry_bytes_fast(variant);
+    lds = (size_t)CTX_SLOTS * TRACE_BLOCK * sizeof(double) + (size_t)dp.stack_cap * TRACE_BLOCK * (size_t)entry;
+    if (lds > 160 * 1024) return set_error(RAYHS_ERR_UNSUPPORTED, "tree depth %d needs %zu B of LDS per workgroup (limit 160 KiB)", dp.stack_cap - 2, lds);
     // persistent grid: as many workgroups as the chip keeps resident
     int *cache = s->grid_cache[exact ? 1 : 0][variant];
     if (cache[0] != (int)lds || cache[1] <= 0) {
         int per_cu = exact ? occupancy_trace_exact(variant, lds) : occupancy_trace_fast(variant, lds);
         if (per_cu <= 0) return set_error(RAYHS_ERR_HIP, "trace kernel cannot be resident (occupancy query returned %d)", per_cu);
+        if (const char *e = std::getenv("RAYHS_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // development knob
         cache[0] = (int)lds; cache[1] = per_cu;
     }
     int wanted = (dp.n_tiles + 3) / 4;  // 4 waves per workgroup, one tile per wave at a time
@@ -347,7 +434,7 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
 }
 
 static int ensure_workspace(const rayhs_scene *s, const DParams &dp) {
-    size_t need = (size_t)std::max(dp.max_depth, 1) * FRAME_SLOTS * (size_t)dp.frame_stride * sizeof(double);
+    size_t need = ((size_t)LANE_SLOTS + (size_t)std::max(dp.max_depth, 1) * FRAME_SLOTS) * (size_t)dp.frame_stride * sizeof(double);
     if (need > s->frames_bytes) {
         if (s->frames) HIP_TRY(hipFree(s->frames));
         s->frames = nullptr; s->frames_bytes = 0;

@@ -1,0 +1,183 @@
+// bvh_build.cpp -- the traversal structure the fast kernels use on the GPU.
+//
+// The reference's tree (src/KDTree.hs:79-90: spatial-median split, leaves of up
+// to 19 triangles, fp64 boxes, both children always visited) is kept verbatim
+// for the exhaustive/validation kernels.  It is a poor fit for a 64-lane
+// machine: large leaves mean many fp64 triangle tests, and 64-byte fp64 boxes
+// double the gather traffic.  Its boxes only decide WHICH triangles get tested;
+// the result of a query is "closest triangle hit, ties by reference order", so
+// any conservative culling structure yields the same answer.  This file builds
+// one that suits CDNA4:
+//   * binary BVH, binned surface-area heuristic, leaves of at most
+//     kMaxLeaf triangles (triangle tests are the expensive fp64 part);
+//   * a node stores BOTH children's boxes as fp32, rounded outward and inflated
+//     by 2^-18 of the mesh extent, 64 bytes per node = one record per visit;
+//   * triangles are re-ordered into BVH leaf order; each keeps its reference
+//     rank so that exact-t ties resolve as in the reference
+//     (src/Geometry.hs:54-57, src/KDTree.hs:113-115).
+#include "bvh_build.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace rayhs {
+
+namespace {
+
+struct Box3 {
+    double lo[3], hi[3];
+    void reset() { for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<double>::infinity(); hi[k] = -lo[k]; } }
+    void grow(const double p[3]) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+    void grow(const Box3 &b) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+    double half_area() const {
+        double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (!(dx >= 0 && dy >= 0 && dz >= 0)) return 0;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+constexpr int kBins = 16;
+constexpr int kMaxLeaf = 2;
+constexpr int kDepthLimit = 28;  // SAH splits only while depth + ceil(log2 n) stays below this; median splits
+                                 // (which halve n) are used otherwise, so inner nodes never sit deeper than this
+
+struct Builder {
+    const std::vector<Box3> &tb;       // per-triangle bounds
+    const std::vector<double> &cen;    // per-triangle centroid, 3 each
+    std::vector<int> order;            // triangle permutation being partitioned in place
+    std::vector<FNodeBuild> nodes;
+    int max_depth = 0;
+
+    Builder(const std::vector<Box3> &b, const std::vector<double> &c) : tb(b), cen(c) {}
+
+    Box3 bounds(int a, int b) const {
+        Box3 r; r.reset();
+        for (int i = a; i < b; i++) r.grow(tb[(size_t)order[(size_t)i]]);
+        return r;
+    }
+
+    // returns child reference: >= 0 inner node, < 0 leaf ~((first << 3) | count)
+    int build(int a, int b, int depth) {
+        max_depth = std::max(max_depth, depth);
+        const int n = b - a;
+        if (n <= kMaxLeaf) return ~((a << 3) | n);
+        // centroid bounds
+        double clo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, chi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+        for (int i = a; i < b; i++)
+            for (int k = 0; k < 3; k++) {
+                double c = cen[3 * (size_t)order[(size_t)i] + (size_t)k];
+                clo[k] = std::min(clo[k], c); chi[k] = std::max(chi[k], c);
+            }
+        int mid = -1;
+        int lg = 0;
+        while ((1 << lg) < n) lg++;
+        if (depth + lg + 1 < kDepthLimit) {
+            double best = DBL_MAX; int best_axis = -1, best_bin = -1;
+            for (int ax = 0; ax < 3; ax++) {
+                double ext = chi[ax] - clo[ax];
+                if (!(ext > 0)) continue;
+                Box3 bb[kBins]; int cnt[kBins];
+                for (int k = 0; k < kBins; k++) { bb[k].reset(); cnt[k] = 0; }
+                double scale = kBins / ext;
+                for (int i = a; i < b; i++) {
+                    int t = order[(size_t)i];
+                    int k = std::min(kBins - 1, std::max(0, (int)((cen[3 * (size_t)t + (size_t)ax] - clo[ax]) * scale)));
+                    bb[k].grow(tb[(size_t)t]); cnt[k]++;
+                }
+                double right_area[kBins]; int right_cnt[kBins];
+                Box3 acc; acc.reset(); int c = 0;
+                for (int k = kBins - 1; k > 0; k--) { acc.grow(bb[k]); c += cnt[k]; right_area[k] = acc.half_area(); right_cnt[k] = c; }
+                acc.reset(); c = 0;
+                for (int k = 0; k < kBins - 1; k++) {
+                    acc.grow(bb[k]); c += cnt[k];
+                    if (c == 0 || right_cnt[k + 1] == 0) continue;
+                    double cost = acc.half_area() * c + right_area[k + 1] * right_cnt[k + 1];
+                    if (cost < best) { best = cost; best_axis = ax; best_bin = k; }
+                }
+            }
+            if (best_axis >= 0) {
+                double ext = chi[best_axis] - clo[best_axis], scale = kBins / ext;
+                auto it = std::partition(order.begin() + a, order.begin() + b, [&](int t) {
+                    int k = std::min(kBins - 1, std::max(0, (int)((cen[3 * (size_t)t + (size_t)best_axis] - clo[best_axis]) * scale)));
+                    return k <= best_bin;
+                });
+                mid = (int)(it - order.begin());
+            }
+        }
+        if (mid <= a || mid >= b) {  // no useful SAH split: median along the widest centroid axis
+            int ax = 0;
+            for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[ax] - clo[ax]) ax = k;
+            mid = a + n / 2;
+            std::nth_element(order.begin() + a, order.begin() + mid, order.begin() + b, [&](int x, int y) {
+                return cen[3 * (size_t)x + (size_t)ax] < cen[3 * (size_t)y + (size_t)ax];
+            });
+        }
+        int id = (int)nodes.size();
+        nodes.emplace_back();
+        Box3 b0 = bounds(a, mid), b1 = bounds(mid, b);
+        int c0 = build(a, mid, depth + 1);
+        int c1 = build(mid, b, depth + 1);
+        FNodeBuild &nd = nodes[(size_t)id];
+        std::memcpy(nd.lo0, b0.lo, sizeof nd.lo0); std::memcpy(nd.hi0, b0.hi, sizeof nd.hi0);
+        std::memcpy(nd.lo1, b1.lo, sizeof nd.lo1); std::memcpy(nd.hi1, b1.hi, sizeof nd.hi1);
+        nd.c0 = c0; nd.c1 = c1;
+        return id;
+    }
+};
+
+}  // namespace
+
+float round_down_f32(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafter(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+float round_up_f32(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafter(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+
+void build_fast_bvh(const double *tri_pos, const std::vector<int> &tri_ids, FastBvh &out) {
+    const int count = (int)tri_ids.size();
+    out.nodes.clear(); out.order.clear(); out.depth = 0;
+    Box3 all; all.reset();
+    std::vector<Box3> tb((size_t)count);
+    std::vector<double> cen(3 * (size_t)count);
+    for (int i = 0; i < count; i++) {
+        const double *p = tri_pos + 9 * (size_t)tri_ids[(size_t)i];
+        Box3 &b = tb[(size_t)i]; b.reset();
+        for (int v = 0; v < 3; v++) b.grow(p + 3 * v);
+        for (int k = 0; k < 3; k++) {
+            // a NaN vertex (the reference can produce them, e.g. rotate about the z axis) must not
+            // poison the tree: give the triangle an empty box; it can never be hit anyway
+            if (!(b.lo[k] <= b.hi[k])) { b.lo[k] = 0; b.hi[k] = 0; }
+            cen[3 * (size_t)i + (size_t)k] = 0.5 * (b.lo[k] + b.hi[k]);
+        }
+        all.grow(b);
+    }
+    for (int k = 0; k < 3; k++) { out.lo[k] = count ? all.lo[k] : 0; out.hi[k] = count ? all.hi[k] : 0; }
+    Builder bl(tb, cen);
+    bl.order.resize((size_t)count);
+    for (int i = 0; i < count; i++) bl.order[(size_t)i] = i;
+    int root;
+    if (count == 0) root = INT32_MIN;
+    else if (count <= kMaxLeaf) {
+        // a single leaf still needs a node so that the kernel has two child slots to test
+        bl.nodes.emplace_back();
+        FNodeBuild &nd = bl.nodes[0];
+        std::memcpy(nd.lo0, all.lo, sizeof nd.lo0); std::memcpy(nd.hi0, all.hi, sizeof nd.hi0);
+        for (int k = 0; k < 3; k++) { nd.lo1[k] = std::numeric_limits<double>::infinity(); nd.hi1[k] = -nd.lo1[k]; }
+        nd.c0 = ~((0 << 3) | count); nd.c1 = INT32_MIN;
+        root = 0;
+    } else root = bl.build(0, count, 0);
+    out.root = root;
+    out.depth = bl.max_depth;
+    out.nodes.swap(bl.nodes);
+    out.order.swap(bl.order);
+}
+
+}  // namespace rayhs

@@ -1,16 +1,19 @@
 // device_scene.h -- HBM-resident scene layout shared by the launcher (abi.cpp)
 // and the trace kernels (trace_kernel.hip).
 //
-// Everything stays fp64 (src/Vec.hs:29-31).  Values the reference recomputes
-// per ray from scene constants (triangle edges, plane bitangent, r*r, Fresnel
-// r0) are computed ONCE on the host with the same fp64 operations, so the
-// stored value is bit-identical to what the reference would derive.
+// Reals stay fp64 (src/Vec.hs:29-31) wherever a value enters the result.
+// Values the reference recomputes per ray from scene constants (triangle edges,
+// plane bitangent, r*r, Fresnel r0) are computed ONCE on the host with the same
+// fp64 operations, so the stored value is bit-identical to what the reference
+// would derive.  Only the culling boxes of the fast traversal structure are
+// fp32 (conservative, see bvh_build.cpp): they never enter a result.
 #pragma once
 #include <stdint.h>
 
 namespace rayhs {
 
-// 64 B, one 64-byte-aligned record per tree node (src/KDTree.hs:59-61).
+// ---- reference tree, used by the exhaustive (validation / counting) kernels ----
+// 64 B per node (src/KDTree.hs:59-61).
 struct alignas(16) DNode {
     double lo[3], hi[3];  // Box (src/KDTree.hs:13-14)
     int32_t a, b;         // inner: left/right child (-1 = Empty); leaf: first triangle, count
@@ -19,10 +22,24 @@ struct alignas(16) DNode {
 };
 static constexpr int32_t DNODE_LEAF = (int32_t)0x80000000;
 
-// 80 B: what triangleIntersection reads (src/Mesh.hs:59-72): p0, e1 = p1-p0, e2 = p2-p0.
+// ---- fast traversal structure (bvh_build.cpp) ----
+// 64 B per node: both children's boxes in fp32, relative to the mesh centre,
+// rounded outward and inflated.  Child reference: >= 0 inner node,
+// < 0 leaf ~((first << 3) | count) into the BVH-ordered triangle array,
+// INT32_MIN = no child.
+struct alignas(16) FNode {
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    int32_t c0, c1;
+    int32_t pad[2];
+};
+static constexpr int32_t FNODE_NONE = (int32_t)0x80000000;
+
+// 80 B: what triangleIntersection reads (src/Mesh.hs:59-72): p0, e1 = p1-p0, e2 = p2-p0,
+// plus the triangle's place in the reference's order for exact-t ties.
 struct alignas(16) DTri {
     double p0[3], e1[3], e2[3];
-    double pad;
+    int32_t rank;        // index in the reference's left-to-right leaf order
+    int32_t leaf_first;  // rank of the first triangle of its reference leaf
 };
 // 128 B: read once per shaded hit (src/Mesh.hs:73-74).
 struct alignas(16) DTriAttr {
@@ -40,8 +57,14 @@ struct DSphere {  // src/Geometry.hs:63, 81-96
     int32_t obj, occluder;
 };
 struct DMesh {
-    int32_t root;                   // -1 = Empty
-    int32_t obj, occluder, pad;
+    int32_t root;                   // reference tree root, -1 = Empty
+    int32_t obj, occluder;
+    int32_t froot;                  // fast BVH root node, FNODE_NONE = no triangles
+    int32_t tri_base;               // first triangle of this mesh in the BVH-ordered arrays
+    int32_t pad;
+    double lo[3], hi[3];            // the reference root's box (src/KDTree.hs:84)
+    double center[3];               // origin of the fp32 box coordinates
+    float flo[3], fhi[3];           // bounds of the mesh in those coordinates, rounded outward and inflated
 };
 struct DObject {  // Material (src/Material.hs:13-19) + ColorMap (src/ColorMap.hs:11-16) of one object
     int32_t mat_kind, cmap_kind, tex_w, tex_h;
@@ -57,16 +80,19 @@ struct DLight {   // src/Light.hs:8-10
 };
 
 struct DScene {
-    const DNode *nodes;
-    const DTri *tris;
-    const DTriAttr *attrs;
+    const DNode *nodes;        // reference tree
+    const DTri *tris;          // reference order
+    const DTriAttr *attrs;     // reference order
+    const FNode *fnodes;       // fast BVH
+    const DTri *ftris;         // BVH leaf order
+    const DTriAttr *fattrs;    // BVH leaf order
     const DPlane *planes;
     const DSphere *spheres;
     const DMesh *meshes;
     const DObject *objects;
     const DLight *lights;
     const double *texels;
-    int32_t n_planes, n_spheres, n_meshes, n_objects, n_lights, n_nodes, n_tris;
+    int32_t n_planes, n_spheres, n_meshes, n_objects, n_lights, n_nodes, n_tris, n_fnodes;
 };
 
 // Camera constants of rayFromPixel / unproject / lookAt (src/Projection.hs:22-46,
@@ -90,7 +116,7 @@ struct DParams {
     int32_t out_format;
     int32_t tiles_x, n_tiles;         // 8x8-pixel tiles over (width x n_rows)
     int32_t stack_cap;                // per-lane LDS stack entries
-    int32_t frame_stride;             // threads in the grid (frame workspace stride)
+    int32_t frame_stride;             // threads in the grid (workspace stride)
 };
 
 // counters[] slots
@@ -99,5 +125,7 @@ enum { CNT_PRIMARY = 0, CNT_REFLECT, CNT_REFRACT, CNT_REFRACT_EXIT, CNT_SHADOW, 
 
 static constexpr int TRACE_BLOCK = 256;     // threads per workgroup (4 waves)
 static constexpr int FRAME_SLOTS = 14;      // doubles per continuation frame
+static constexpr int LANE_SLOTS = 9;        // per-lane doubles kept in the global workspace besides frames (view dir, sample sum, light term)
+static constexpr int CTX_SLOTS = 12;        // per-lane doubles parked in LDS across a shadow / exit query (p, n, cd, A)
 
 }  // namespace rayhs

@@ -13,28 +13,40 @@
 //   lightAt, fresnel, diffuse, colorAt      src/Light.hs:12-17, src/Material.hs:22-33, src/ColorMap.hs:18-58
 //
 // How it runs here (not how the reference runs):
-//   * Persistent waves: a fixed grid sized to the chip; each 64-lane wave pulls
-//     8x8-pixel tiles from one atomic ticket counter until the frame is done.
+//   * Persistent waves: a fixed grid sized to the chip; each 64-lane wave draws
+//     pixels (in 8x8-tile order) from one atomic ticket counter into a wave-local
+//     pool and refills a lane the moment its pixel is finished (__ballot /
+//     popcount ranking), until the frame is done.
 //   * The recursion of irradiance/specular is an explicit per-lane state
 //     machine.  Every lane, whatever its shading state, funnels into ONE scene
 //     query site per iteration, so primary, shadow, reflection and refraction
 //     rays of different pixels share the traversal loop of a wave.
-//   * Tree traversal uses a per-lane node stack in LDS (level-major, so a
-//     wave's accesses are bank-conflict free), near-child-first ordering by the
-//     split axis, and pruning against the closest hit so far; shadow queries
-//     stop at the first occluder.  The reference visits both children always;
-//     the winner is the same because ties are resolved by the reference's rule
-//     (first triangle in a leaf, right-most leaf, first scene object).
-//   * All arithmetic is fp64 like the reference.  Built twice: "exact"
-//     (-ffp-contract=off, same operations as the reference/oracle) and "fast"
-//     (fused multiply-add allowed).
-//
-// Continuation frames of suspended irradiance calls live in a global workspace
-// (14 doubles per level per lane, slot-major so lanes coalesce).
+//   * Mesh traversal uses the BVH of bvh_build.cpp: 64-byte nodes holding both
+//     children's boxes as conservative fp32, a per-lane stack of inner-node
+//     indices in LDS (level-major: bank-conflict free), nearest child first,
+//     pruning against the closest hit so far, any-hit exit for shadow queries,
+//     and a while-while loop that postpones leaves so that the fp64 triangle
+//     tests run with many lanes active.  Boxes only decide which triangles are
+//     tested; the winner is the reference's because every triangle test is the
+//     reference's fp64 Moller-Trumbore and ties are resolved by its rule (first
+//     triangle in a leaf, right-most leaf, first scene object).
+//   * The exhaustive kernels instead walk the reference's own tree (fp64
+//     boxes, both children always) and visit exactly its node set.
+//   * Everything that enters a result is fp64 like the reference.  Built twice:
+//     "exact" (-ffp-contract=off, same operations as the reference/oracle) and
+//     "fast" (fused multiply-add allowed).
+//   * To run 4 waves per SIMD the kernel must fit 128 VGPRs: the shading context
+//     of a hit (p, n, cd, A: 12 doubles per lane) is parked in LDS across shadow
+//     and exit queries; the view direction, the sample sum and the continuation
+//     frames of suspended irradiance calls live in a global workspace (slot-major
+//     so lanes coalesce).
 #include <hip/hip_runtime.h>
 
 #include "device_scene.h"
 
+#ifndef RAYHS_FP32_ROOT
+#define RAYHS_FP32_ROOT 1  // 1: conservative fp32 root cull; 0: the reference's exact fp64 root test
+#endif
 #ifndef RAYHS_KERNEL_SUFFIX
 #define RAYHS_KERNEL_SUFFIX fast
 #endif
@@ -46,8 +58,16 @@ namespace rayhs {
 struct V3 { double x, y, z; };
 #define DEV static __device__ __forceinline__
 
+// Scene tables (planes, spheres, meshes, objects, lights) are read through the constant address
+// space: a wave-uniform index then becomes a scalar load into SGPRs instead of 64 identical
+// per-lane loads into VGPRs.  LDS columns are addressed through explicit local-address-space
+// pointers so that they compile to ds_read/ds_write rather than flat accesses.
+template <class T> using cptr = const T __attribute__((address_space(4))) *;
+template <class T> static __device__ __forceinline__ cptr<T> as_const(const T *p) { return (cptr<T>)(unsigned long long)p; }
+typedef double __attribute__((address_space(3))) *lds_dptr;
+
 DEV V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-DEV V3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+template <class P> DEV V3 ld3(P p) { return mk(p[0], p[1], p[2]); }
 DEV V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 DEV V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 DEV V3 mulv(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
@@ -95,7 +115,7 @@ DEV double mod_floor(double n, double d) {
 DEV long long imod(long long a, long long m) { long long r = a % m; if (r != 0 && ((r < 0) != (m < 0))) r += m; return r; }
 
 // colorAt (src/ColorMap.hs:18-58)
-DEV V3 color_at(const DObject &o, const double *texels, double u, double v) {
+template <class OB> DEV V3 color_at(const OB &o, const double *texels, double u, double v) {
     if (o.cmap_kind == 0) return ld3(o.c1);
     if (o.cmap_kind == 1) {
         double s = o.size;
@@ -137,6 +157,15 @@ DEV double sample01(uint64_t seed_mixed, uint64_t pixel, uint32_t sample, uint32
     return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// rare paths kept out of line so that their temporaries do not inflate the kernel's register budget
+static __device__ __attribute__((noinline)) void polar_uv(V3 n, double &u, double &v) {  // polar, src/Geometry.hs:96
+    u = kPiInv * atan(n.z / n.x);
+    v = kPiInv * acos(n.y);
+}
+static __device__ __attribute__((noinline)) V3 color_at_slow(cptr<DObject> objects, int obj, const double *texels, double u, double v) {
+    return color_at(objects[obj], texels, u, v);
+}
+
 struct Ray { V3 o, d; };
 
 // rayFromPixel (src/Projection.hs:22-39); camera constants precomputed on the host
@@ -162,27 +191,35 @@ enum : int { Q_NONE = 0, Q_CLOSEST, Q_SHADOW };
 
 struct Counters { unsigned long long c[10]; };
 
-template <bool EXH, bool COUNT>
+DEV float f32_up(double v) {  // smallest float >= v (v >= 0 here)
+    float f = (float)v;
+    if ((double)f < v) f = __uint_as_float(__float_as_uint(f) + 1u);
+    return f;
+}
+
+template <bool EXH, bool COUNT, typename StackT>
 struct Tracer {
+    typedef StackT __attribute__((address_space(3))) *stack_ptr;
     const DScene &sc;
-    int *stack;      // this lane's LDS column: stack[level * TRACE_BLOCK]
+    stack_ptr stack;  // this lane's LDS column: stack[level * TRACE_BLOCK]
     Counters &cnt;
 
     // closest-hit record
     double bt, bu, bv;
-    int bobj, btri, bleaf;
+    int bobj, btri, bleaf, brank;
     int bprim;  // winning plane index i, or sphere index as -(i + 2); -1 for a triangle / miss
+    bool bref;  // btri indexes the reference-order arrays (hit found by the reference tree), else the BVH-order ones
 
-    __device__ Tracer(const DScene &s, int *st, Counters &c) : sc(s), stack(st), cnt(c) {}
+    __device__ Tracer(const DScene &s, stack_ptr st, Counters &c) : sc(s), stack(st), cnt(c) {}
 
     // ---- analytic primitives (src/Geometry.hs:68-96) ----
-    __device__ __forceinline__ bool plane_t(const DPlane &pl, const Ray &r, double &t) {
+    template <class PL> __device__ __forceinline__ bool plane_t(const PL &pl, const Ray &r, double &t) {
         double dDotn = dot(r.d, ld3(pl.n));
         double time = dot(ld3(pl.n), sub(ld3(pl.p), r.o)) / dDotn;
         t = time;
         return fabs(dDotn) > 0 && time > 0;
     }
-    __device__ __forceinline__ bool sphere_t(const DSphere &s, const Ray &r, double a, double &t) {
+    template <class SP> __device__ __forceinline__ bool sphere_t(const SP &s, const Ray &r, double a, double &t) {
         V3 oc = sub(r.o, ld3(s.c));
         double b = 2.0 * dot(r.d, oc);
         double c = dot(oc, oc) - s.r2;
@@ -197,10 +234,10 @@ struct Tracer {
     }
 
     // rayInterBox (src/KDTree.hs:39-56); returns pass and tmin
-    __device__ __forceinline__ bool box_test(const DNode &nd, const Ray &r, V3 inv, double &tmin_out) {
-        double t1 = inv.x * (nd.lo[0] - r.o.x), t2 = inv.x * (nd.hi[0] - r.o.x);
-        double t3 = inv.y * (nd.lo[1] - r.o.y), t4 = inv.y * (nd.hi[1] - r.o.y);
-        double t5 = inv.z * (nd.lo[2] - r.o.z), t6 = inv.z * (nd.hi[2] - r.o.z);
+    template <class BP> __device__ __forceinline__ bool box_test(BP lo, BP hi, const Ray &r, V3 inv, double &tmin_out) {
+        double t1 = inv.x * (lo[0] - r.o.x), t2 = inv.x * (hi[0] - r.o.x);
+        double t3 = inv.y * (lo[1] - r.o.y), t4 = inv.y * (hi[1] - r.o.y);
+        double t5 = inv.z * (lo[2] - r.o.z), t6 = inv.z * (hi[2] - r.o.z);
         double tmin = hs_max(hs_max(hs_min(t1, t2), hs_min(t3, t4)), hs_min(t5, t6));
         double tmax = hs_min(hs_min(hs_max(t1, t2), hs_max(t3, t4)), hs_max(t5, t6));
         tmin_out = tmin;
@@ -221,400 +258,536 @@ struct Tracer {
         return !(fabs(det) < kEps || u < 0 || u > 1 || v < 0 || (u + v) > 1 || t < kEps);
     }
 
+    // for a point light a hit occludes iff sqrDist origin light > sqrDist origin hit (src/RayHs.hs:84-87)
+    __device__ __forceinline__ bool in_front(const Ray &r, double t, bool point_light, double light_d2) {
+        if (!point_light) return true;
+        V3 pos = add(r.o, scl(t, r.d));
+        V3 dd = sub(r.o, pos);
+        return light_d2 > dot(dd, dd);
+    }
+
+    // tie rule: first triangle inside a leaf, right-most leaf inside a tree (src/Geometry.hs:54-57,
+    // src/KDTree.hs:113-115), first object in the scene (src/RayHs.hs:67-71)
+    __device__ __forceinline__ bool offer(double t, double u, double v, int obj, int tri, int leaf_first, int rank) {
+        bool take = t < bt;
+        if (t == bt) {
+            if (obj != bobj) take = obj < bobj;
+            else if (leaf_first != bleaf) take = leaf_first > bleaf;
+            else take = rank < brank;
+        }
+        if (take) { bt = t; bu = u; bv = v; bobj = obj; btri = tri; bleaf = leaf_first; brank = rank; bprim = -1; }
+        return take;
+    }
+
+    // conservative fp32 slab test of one child box of the fast BVH; t is relative to the shifted origin
+    __device__ __forceinline__ bool fbox(const float *lo, const float *hi, float ox, float oy, float oz, float ix, float iy, float iz,
+                                         float limf, float &tnear) {
+        float t1 = (lo[0] - ox) * ix, t2 = (hi[0] - ox) * ix;
+        float t3 = (lo[1] - oy) * iy, t4 = (hi[1] - oy) * iy;
+        float t5 = (lo[2] - oz) * iz, t6 = (hi[2] - oz) * iz;
+        // fminf/fmaxf drop a NaN operand (0 * inf when the origin lies on a slab plane of a zero direction axis)
+        float tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+        float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+        tnear = tn;
+        return tf >= fmaxf(tn, 0.0f) && tn <= limf;
+    }
+
     // One scene query for this lane.  kind == Q_CLOSEST fills the b* record
     // (bobj = -1 on a miss); kind == Q_SHADOW returns whether any non-Emmit
-    // object occludes the light (src/RayHs.hs:74-87): for a point light a hit
-    // occludes iff sqrDist origin light > sqrDist origin hit.
+    // object occludes the light (src/RayHs.hs:74-87).
     __device__ bool query(int kind, const Ray &r, bool point_light, double light_d2, double light_dist) {
         const bool active = kind != Q_NONE;
         const bool shadow = kind == Q_SHADOW;
         bool occluded = false;
-        bt = __builtin_inf(); bu = 0; bv = 0; bobj = -1; btri = -1; bleaf = -1; bprim = -1;
+        bt = __builtin_inf(); bu = 0; bv = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH;
 
         // ---- planes and spheres: wave-uniform loops, scene constants via scalar loads
         for (int i = 0; i < sc.n_planes; i++) {
-            const DPlane &pl = sc.planes[i];
+            const auto &pl = as_const(sc.planes)[i];
             if (!active || (shadow && !EXH && (occluded || !pl.occluder))) continue;
             if (COUNT) cnt.c[CNT_PRIMS]++;
             double t;
             if (plane_t(pl, r, t)) {
-                if (shadow) {
-                    if (pl.occluder) {
-                        bool front = true;
-                        if (point_light) { V3 pos = add(r.o, scl(t, r.d)); V3 dd = sub(r.o, pos); front = light_d2 > dot(dd, dd); }
-                        occluded = occluded || front;
-                    }
-                } else if (t < bt || (t == bt && pl.obj < bobj)) { bt = t; bobj = pl.obj; bprim = i; }
+                if (shadow) { if (pl.occluder) occluded = occluded || in_front(r, t, point_light, light_d2); }
+                else if (t < bt || (t == bt && pl.obj < bobj)) { bt = t; bobj = pl.obj; bprim = i; }
             }
         }
         const double a = dot(r.d, r.d);
         for (int i = 0; i < sc.n_spheres; i++) {
-            const DSphere &s = sc.spheres[i];
+            const auto &s = as_const(sc.spheres)[i];
             if (!active || (shadow && !EXH && (occluded || !s.occluder))) continue;
             if (COUNT) cnt.c[CNT_PRIMS]++;
             double t;
             if (sphere_t(s, r, a, t)) {
-                if (shadow) {
-                    if (s.occluder) {
-                        bool front = true;
-                        if (point_light) { V3 pos = add(r.o, scl(t, r.d)); V3 dd = sub(r.o, pos); front = light_d2 > dot(dd, dd); }
-                        occluded = occluded || front;
-                    }
-                } else if (t < bt || (t == bt && s.obj < bobj)) { bt = t; bobj = s.obj; bprim = -(i + 2); }
+                if (shadow) { if (s.occluder) occluded = occluded || in_front(r, t, point_light, light_d2); }
+                else if (t < bt || (t == bt && s.obj < bobj)) { bt = t; bobj = s.obj; bprim = -(i + 2); }
             }
         }
+        if (sc.n_meshes == 0) return occluded;
 
-        // ---- meshes: per-lane traversal with the LDS stack
-        if (sc.n_meshes > 0) {
-            V3 inv = mk(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);  // src/KDTree.hs:46-48
-            for (int m = 0; m < sc.n_meshes; m++) {
-                const DMesh &me = sc.meshes[m];
-                int node = me.root;
-                if (!active || (shadow && !EXH && (occluded || !me.occluder))) node = -1;
-                int sp = 0;
-                while (true) {
-                    if (node < 0) {
+        // The reference's slab test multiplies by 1/d: with a zero direction component and a box plane
+        // through the origin it computes 0 * inf = NaN and may reject a box the ray does touch
+        // (src/KDTree.hs:39-56).  Its boxes are therefore NOT a conservative cull for such rays, and only
+        // its own tree reproduces its answer: those (rare) lanes walk the reference tree.
+        const bool by_reference = EXH || r.d.x == 0 || r.d.y == 0 || r.d.z == 0;
+        if (EXH || __ballot(active && by_reference) != 0ull)
+            occluded = meshes_reference(active && by_reference, shadow, r, point_light, light_d2, occluded);
+        if (!EXH) occluded = meshes_fast(active && !by_reference, shadow, r, point_light, light_d2, light_dist, occluded);
+        return occluded;
+    }
+
+    // ---- the reference's own tree, both children always (src/KDTree.hs:96-115)
+    __device__ __forceinline__ bool meshes_reference(bool active, bool shadow, const Ray &r, bool point_light, double light_d2, bool occluded) {
+        const V3 inv = mk(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);  // src/KDTree.hs:46-48
+        for (int m = 0; m < sc.n_meshes; m++) {
+            const auto &me = as_const(sc.meshes)[m];
+            // outside the exhaustive kernels a shadow query may stop at its first occluder and skip Emmit objects
+            int node = active && (EXH || !(shadow && (occluded || !me.occluder))) ? me.root : -1;
+            int sp = 0;
+            while (true) {
+                if (node < 0) {
+                    if (sp == 0) break;
+                    sp--;
+                    node = (int)stack[sp * TRACE_BLOCK];
+                    continue;
+                }
+                const DNode nd = sc.nodes[node];
+                if (COUNT) cnt.c[CNT_NODES]++;
+                double tmin;
+                int next = -1;
+                if (box_test(nd.lo, nd.hi, r, inv, tmin)) {
+                    if (nd.flags & DNODE_LEAF) {
+                        const int first = nd.a, last = nd.a + nd.b;
+                        for (int k = first; k < last; k++) {
+                            const DTri tr = sc.tris[k];
+                            if (COUNT) cnt.c[CNT_TRIS]++;
+                            double t, u, v;
+                            if (tri_test(tr, r, t, u, v)) {
+                                if (shadow) { if (me.occluder) occluded = occluded || in_front(r, t, point_light, light_d2); }
+                                else if (offer(t, u, v, me.obj, k, tr.leaf_first, tr.rank)) bref = true;
+                            }
+                        }
+                    } else {
+                        int l = nd.a, rr = nd.b;
+                        if (l >= 0 && rr >= 0) { stack[sp * TRACE_BLOCK] = (StackT)rr; sp++; next = l; }
+                        else next = l >= 0 ? l : rr;
+                    }
+                }
+                node = next;
+            }
+        }
+        return occluded;
+    }
+
+    // ---- fast BVH: fp32 conservative boxes, fp64 triangle tests
+    __device__ __forceinline__ bool meshes_fast(bool active, bool shadow, const Ray &r, bool point_light, double light_d2, double light_dist, bool occluded) {
+        // reciprocal direction in fp32 (1 ulp): every use below is a conservative cull, never a result
+        const float ix = __builtin_amdgcn_rcpf((float)r.d.x), iy = __builtin_amdgcn_rcpf((float)r.d.y), iz = __builtin_amdgcn_rcpf((float)r.d.z);
+        for (int m = 0; m < sc.n_meshes; m++) {
+            const auto &me = as_const(sc.meshes)[m];
+            bool go = active && me.froot != FNODE_NONE && !(shadow && (occluded || !me.occluder));
+            const double lim = shadow ? light_dist : bt;
+            // root cull in mesh-centred fp32.  The origin may be far from the mesh, so its rounding error
+            // (2^-24 of its distance) is added to the box as an explicit margin.
+            const float cxo = (float)(r.o.x - me.center[0]), cyo = (float)(r.o.y - me.center[1]), czo = (float)(r.o.z - me.center[2]);
+            const float mg = 4.76837158e-7f * fmaxf(fmaxf(fabsf(cxo), fabsf(cyo)), fabsf(czo));  // 2^-21 * max |o - c|
+            float tn_root;
+            {
+                float lo[3] = {me.flo[0] - mg, me.flo[1] - mg, me.flo[2] - mg};
+                float hi[3] = {me.fhi[0] + mg, me.fhi[1] + mg, me.fhi[2] + mg};
+                if (COUNT && go) cnt.c[CNT_NODES]++;
+                go = go && fbox(lo, hi, cxo, cyo, czo, ix, iy, iz, f32_up(lim), tn_root);
+            }
+            // shift the origin to (just before) the entry point, so that its fp32 rounding error inside the
+            // traversal (2^-24 of the mesh size) is far inside the 2^-18 inflation of the boxes
+            const double t_enter = go && tn_root > 0 ? (double)(tn_root * 0.99999905f) : 0.0;
+            const float ox = (float)((r.o.x + t_enter * r.d.x) - me.center[0]);
+            const float oy = (float)((r.o.y + t_enter * r.d.y) - me.center[1]);
+            const float oz = (float)((r.o.z + t_enter * r.d.z) - me.center[2]);
+            float limf = f32_up(lim - t_enter);
+            int cur = go ? me.froot : FNODE_NONE;
+            int sp = 0;
+            int pend_a = FNODE_NONE, pend_b = FNODE_NONE;
+            while (true) {
+                // phase 1: walk inner nodes until this lane holds a leaf (or runs out of nodes)
+                while (pend_a == FNODE_NONE) {
+                    if (cur == FNODE_NONE) {
                         if (sp == 0) break;
                         sp--;
-                        node = stack[sp * TRACE_BLOCK];
-                        continue;
+                        cur = (int)stack[sp * TRACE_BLOCK];
                     }
-                    const DNode nd = sc.nodes[node];
-                    if (COUNT) cnt.c[CNT_NODES]++;
-                    double tmin;
-                    bool pass = box_test(nd, r, inv, tmin);
-                    if (!EXH) {
-                        // prune: nothing behind the best hit / the light can matter.  The slack keeps
-                        // the decision conservative against rounding of tmin vs. a triangle's t.
-                        double lim = shadow ? light_dist : bt;
-                        if (tmin > lim + 1e-9 * (1 + fabs(lim))) pass = false;
-                    }
-                    int next = -1;
-                    if (pass) {
-                        if (nd.flags & DNODE_LEAF) {
-                            const int first = nd.a, last = nd.a + nd.b;
-                            for (int k = first; k < last; k++) {
-                                if (!EXH && shadow && occluded) break;
-                                const DTri tr = sc.tris[k];
-                                if (COUNT) cnt.c[CNT_TRIS]++;
-                                double t, u, v;
-                                if (tri_test(tr, r, t, u, v)) {
-                                    if (shadow) {
-                                        if (me.occluder) {
-                                            bool front = true;
-                                            if (point_light) { V3 pos = add(r.o, scl(t, r.d)); V3 dd = sub(r.o, pos); front = light_d2 > dot(dd, dd); }
-                                            occluded = occluded || front;
-                                        }
-                                    } else {
-                                        // tie rule: first triangle inside a leaf, right-most leaf inside a
-                                        // tree (src/Geometry.hs:54-57, src/KDTree.hs:113-115), first object
-                                        // in the scene (src/RayHs.hs:67-71)
-                                        bool take = t < bt;
-                                        if (t == bt) {
-                                            if (me.obj != bobj) take = me.obj < bobj;
-                                            else take = first > bleaf;
-                                        }
-                                        if (take) { bt = t; bu = u; bv = v; bobj = me.obj; btri = k; bleaf = first; bprim = -1; }
-                                    }
-                                }
-                            }
-                        } else {
-                            int l = nd.a, rr = nd.b;
-                            if (!EXH) {
-                                // near child first: left holds barycentres below the split (src/KDTree.hs:84-87)
-                                int ax = nd.flags & 3;
-                                double dax = ax == 0 ? r.d.x : ax == 1 ? r.d.y : r.d.z;
-                                if (dax < 0) { int tmp = l; l = rr; rr = tmp; }
-                            }
-                            if (l >= 0 && rr >= 0) { stack[sp * TRACE_BLOCK] = rr; sp++; next = l; }
-                            else next = l >= 0 ? l : rr;
+                    const FNode nd = sc.fnodes[cur];
+                    float tn0, tn1;
+                    bool h0 = nd.c0 != FNODE_NONE && fbox(nd.lo0, nd.hi0, ox, oy, oz, ix, iy, iz, limf, tn0);
+                    bool h1 = nd.c1 != FNODE_NONE && fbox(nd.lo1, nd.hi1, ox, oy, oz, ix, iy, iz, limf, tn1);
+                    if (COUNT) cnt.c[CNT_NODES] += (nd.c0 != FNODE_NONE) + (nd.c1 != FNODE_NONE);
+                    const bool l0 = h0 && nd.c0 < 0, l1 = h1 && nd.c1 < 0;  // hit leaves
+                    const bool i0 = h0 && nd.c0 >= 0, i1 = h1 && nd.c1 >= 0;  // hit inner children
+                    if (l0 && l1) {  // nearer leaf first
+                        bool near0 = tn0 <= tn1;
+                        pend_a = near0 ? nd.c0 : nd.c1;
+                        pend_b = near0 ? nd.c1 : nd.c0;
+                    } else if (l0) pend_a = nd.c0;
+                    else if (l1) pend_a = nd.c1;
+                    int next = FNODE_NONE;
+                    if (i0 && i1) {
+                        bool near0 = tn0 <= tn1;
+                        next = near0 ? nd.c0 : nd.c1;
+                        stack[sp * TRACE_BLOCK] = (StackT)(near0 ? nd.c1 : nd.c0);
+                        sp++;
+                    } else if (i0) next = nd.c0;
+                    else if (i1) next = nd.c1;
+                    cur = next;
+                }
+                if (pend_a == FNODE_NONE) break;
+                // phase 2: the postponed leaf, with the reference's fp64 triangle test on the ORIGINAL ray
+                {
+                    const int ref = ~pend_a;
+                    const int first = me.tri_base + (ref >> 3), n = ref & 7;
+                    for (int k = first; k < first + n; k++) {
+                        const DTri tr = sc.ftris[k];
+                        if (COUNT) cnt.c[CNT_TRIS]++;
+                        double t, u, v;
+                        if (tri_test(tr, r, t, u, v)) {
+                            if (shadow) occluded = occluded || in_front(r, t, point_light, light_d2);
+                            else if (offer(t, u, v, me.obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - t_enter); }
                         }
                     }
-                    if (!EXH && shadow && occluded) { sp = 0; next = -1; }
-                    node = next;
+                    pend_a = pend_b;
+                    pend_b = FNODE_NONE;
                 }
+                if (shadow && occluded) break;
             }
         }
         return occluded;
     }
 };
 
-DEV void frame_store(double *ws, int stride, int level, int slot, double v) { ws[(size_t)(level * FRAME_SLOTS + slot) * (size_t)stride] = v; }
-DEV double frame_load(const double *ws, int stride, int level, int slot) { return ws[(size_t)(level * FRAME_SLOTS + slot) * (size_t)stride]; }
-DEV void frame_store3(double *ws, int stride, int level, int slot, V3 v) {
-    frame_store(ws, stride, level, slot, v.x); frame_store(ws, stride, level, slot + 1, v.y); frame_store(ws, stride, level, slot + 2, v.z);
-}
-DEV V3 frame_load3(const double *ws, int stride, int level, int slot) {
-    return mk(frame_load(ws, stride, level, slot), frame_load(ws, stride, level, slot + 1), frame_load(ws, stride, level, slot + 2));
-}
-// frame slots
+// ---- global per-lane workspace: LANE_SLOTS lane slots, then FRAME_SLOTS per continuation level ----
+enum : int { LS_V = 0, LS_SUM = 3, LS_TERM = 6 };
 enum : int { FS_KIND = 0, FS_DEPTH = 1, FS_F = 2, FS_S = 3, FS_K = 4, FS_A = 5, FS_RO = 8, FS_RD = 11 };
+DEV void ws_store(double *ws, int stride, int slot, double v) { ws[(size_t)slot * (size_t)stride] = v; }
+DEV double ws_load(const double *ws, int stride, int slot) { return ws[(size_t)slot * (size_t)stride]; }
+DEV void ws_store3(double *ws, int stride, int slot, V3 v) { ws_store(ws, stride, slot, v.x); ws_store(ws, stride, slot + 1, v.y); ws_store(ws, stride, slot + 2, v.z); }
+DEV V3 ws_load3(const double *ws, int stride, int slot) { return mk(ws_load(ws, stride, slot), ws_load(ws, stride, slot + 1), ws_load(ws, stride, slot + 2)); }
+DEV int fslot(int level, int s) { return LANE_SLOTS + level * FRAME_SLOTS + s; }
 
-template <bool EXH, bool COUNT>
+// ---- LDS context slots (12 doubles per lane) ----
+enum : int { CX_P = 0, CX_N = 3, CX_CD = 6, CX_A = 9 };
+DEV void cx_store3(lds_dptr cx, int slot, V3 v) { cx[slot * TRACE_BLOCK] = v.x; cx[(slot + 1) * TRACE_BLOCK] = v.y; cx[(slot + 2) * TRACE_BLOCK] = v.z; }
+DEV V3 cx_load3(lds_dptr cx, int slot) { return mk(cx[slot * TRACE_BLOCK], cx[(slot + 1) * TRACE_BLOCK], cx[(slot + 2) * TRACE_BLOCK]); }
+
+template <bool EXH, bool COUNT, typename StackT>
 static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DParams &prm, void *out,
                                   unsigned long long *counters, unsigned int *ticket, double *frames) {
-    extern __shared__ int lds_stack[];
+    extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int gtid = blockIdx.x * TRACE_BLOCK + tid;
     Counters cnt;
     for (int i = 0; i < 10; i++) cnt.c[i] = 0;
-    Tracer<EXH, COUNT> tr(sc, lds_stack + tid, cnt);
+    lds_dptr cx = (lds_dptr)lds + tid;                                                  // context column
+    typedef StackT __attribute__((address_space(3))) *stack_ptr;
+    stack_ptr stk = (stack_ptr)((lds_dptr)lds + CTX_SLOTS * TRACE_BLOCK) + tid;          // stack column
+    Tracer<EXH, COUNT, StackT> tr(sc, stk, cnt);
     double *ws = frames + gtid;
     const int stride = prm.frame_stride;
     const uint64_t seed_mixed = mix64(prm.seed + 0x9e3779b97f4a7c15ULL);
 
-    // per-lane path state
+    // per-lane state that stays in registers across a scene query
     int state = ST_DONE;
     int px = 0, lrow = 0, yrow = 0, sample = 0;
-    V3 sum = mk(0, 0, 0);
     int depth = 0, fsp = 0;
     Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
     int qkind = Q_NONE;
     bool q_point = false; double q_d2 = 0, q_dist = 0;
-    // shading context kept across shadow / exit queries
-    V3 c_p = mk(0, 0, 0), c_n = mk(0, 0, 0), c_v = mk(0, 0, 0), c_cd = mk(0, 0, 0), c_A = mk(0, 0, 0), c_term = mk(0, 0, 0);
     int c_obj = 0, c_li = 0;
     bool occluded = false;
-    bool have_pixel = false;
+
+    // Work items are pixel slots in 8x8-tile order (item >> 6 = tile, item & 63 = position in the tile).
+    // A wave draws chunks of kChunk items from the global ticket into a wave-local pool and hands them to
+    // its idle lanes, so a lane that finishes its pixel gets the next one at once instead of waiting for
+    // the slowest pixel of a tile.  A fresh wave still starts on one whole, coherent tile.
+#ifndef RAYHS_REFILL_MIN
+#define RAYHS_REFILL_MIN 1
+#endif
+#ifndef RAYHS_CHUNK
+#define RAYHS_CHUNK 64
+#endif
+    constexpr unsigned kChunk = RAYHS_CHUNK;
+    const unsigned total_items = (unsigned)prm.n_tiles * 64u;
+    unsigned pool_next = 0, pool_end = 0;
+    bool exhausted = false;
 
     while (true) {
-        // ---- tile fetch: the whole wave takes the next 8x8 tile when every lane is idle
-        if (__ballot(state != ST_DONE) == 0ull) {
-            unsigned int tile = 0;
-            if (lane == 0) tile = atomicAdd(ticket, 1u);
-            tile = __shfl(tile, 0);
-            if (tile >= (unsigned)prm.n_tiles) break;
-            int ty = (int)tile / prm.tiles_x, tx = (int)tile - ty * prm.tiles_x;
-            px = tx * 8 + (lane & 7);
-            lrow = ty * 8 + (lane >> 3);
-            have_pixel = px < prm.width && lrow < prm.n_rows;
-            if (have_pixel) {
-                // local row -> image row (stripe interleave, include/rayhs.h)
-                int s_local = lrow / prm.stripe_rows, within = lrow - s_local * prm.stripe_rows;
-                yrow = prm.row0 + (s_local * prm.stripe_count + prm.stripe_rank) * prm.stripe_rows + within;
-                sample = 0;
-                sum = mk(0, 0, 0);
-                state = ST_NEW_SAMPLE;
+        unsigned long long idle = __ballot(state == ST_DONE);
+        if (__popcll(idle) < RAYHS_REFILL_MIN) idle = 0ull;
+        while (idle != 0ull && !exhausted) {  // wave-uniform
+            if (pool_next == pool_end) {
+                unsigned c = 0;
+                if (lane == 0) c = atomicAdd(ticket, kChunk);
+                c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+                pool_next = c;
+                pool_end = c + kChunk < total_items ? c + kChunk : total_items;
+                if (c >= total_items) { exhausted = true; break; }
             }
+            const unsigned avail = pool_end - pool_next;
+            const unsigned rank = (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+            const bool take = ((idle >> lane) & 1ull) && rank < avail;
+            if (take) {
+                const unsigned item = pool_next + rank;
+                const int tile = (int)(item >> 6), within = (int)(item & 63u);
+                const int ty = tile / prm.tiles_x, tx = tile - ty * prm.tiles_x;
+                px = tx * 8 + (within & 7);
+                lrow = ty * 8 + (within >> 3);
+                if (px < prm.width && lrow < prm.n_rows) {
+                    // local row -> image row (stripe interleave, include/rayhs.h)
+                    int s_local = lrow / prm.stripe_rows, in_stripe = lrow - s_local * prm.stripe_rows;
+                    yrow = prm.row0 + (s_local * prm.stripe_count + prm.stripe_rank) * prm.stripe_rows + in_stripe;
+                    sample = 0;
+                    if (prm.spp > 1) ws_store3(ws, stride, LS_SUM, mk(0, 0, 0));
+                    state = ST_NEW_SAMPLE;
+                }
+            }
+            const unsigned long long took = __ballot(take);
+            pool_next += (unsigned)__popcll(took);
+            idle &= ~took;
         }
+        if (exhausted && __ballot(state != ST_DONE) == 0ull) break;
 
-        // ---- advance: consume the last query's answer, run shading up to the next query
+        // ---- advance: consume the last query's answer, run shading up to the next query.
+        // Straight-line sections (hit / shadow / exit -> lights -> specular -> return -> next sample)
+        // keep the live ranges short; everything declared in this block dies before the query below.
         qkind = Q_NONE;
         if (state != ST_DONE) {
             V3 result = mk(0, 0, 0);
-            // sub-steps inside advance
-            enum : int { A_DISPATCH, A_LIGHT_NEXT, A_SPEC, A_RETURN, A_QUERY_READY };
-            int step = A_DISPATCH;
+            V3 c_p = mk(0, 0, 0), c_n = mk(0, 0, 0), c_cd = mk(0, 0, 0), c_A = mk(0, 0, 0);
+            enum : int { A_NONE, A_LIGHT_NEXT, A_SPEC, A_RETURN, A_QUERY_READY };
+            int step = A_NONE;
             bool spec_with_A = false;
-            while (step != A_QUERY_READY && state != ST_DONE) {
-                if (step == A_DISPATCH) {
-                    if (state == ST_NEW_SAMPLE) {
-                        // pixelCoord (src/Image.hs:31-32) + optional sample offset (src/RayHs.hs:178-188)
-                        double fx = (double)px, fy = (double)yrow;
-                        if (prm.spp > 1) {
-                            uint64_t pixel = (uint64_t)px + (uint64_t)prm.width * (uint64_t)yrow;
-                            fx = fx + (sample01(seed_mixed, pixel, (uint32_t)sample, 0, (uint32_t)prm.spp) - 0.5);
-                            fy = fy + (sample01(seed_mixed, pixel, (uint32_t)sample, 1, (uint32_t)prm.spp) - 0.5);
+
+            if (state == ST_HIT) {
+                // traceRay (src/RayHs.hs:149-154)
+                if (tr.bobj < 0) { result = mk(0, 0, 0); step = A_RETURN; }
+                else {
+                    const auto &ob = as_const(sc.objects)[tr.bobj];
+                    if (COUNT) cnt.c[CNT_SHADED]++;
+                    c_obj = tr.bobj;
+                    ws_store3(ws, stride, LS_V, ray.d);
+                    c_p = add(ray.o, scl(tr.bt, ray.d));  // rayAt (src/Geometry.hs:27-29)
+                    double hu = 0, hv = 0;
+                    const int mat_kind = ob.mat_kind;
+                    const bool need_uv = ((mat_kind == 1 || mat_kind == 2) && ob.cmap_kind != 0) || mat_kind == 6;
+                    if (tr.btri >= 0) {
+                        const DTriAttr &at = (tr.bref ? sc.attrs : sc.fattrs)[tr.btri];
+                        double u = tr.bu, v = tr.bv, w = 1 - u - v;
+                        // barycentricInterp u n1 v n2 (1-u-v) n0 (src/Mesh.hs:53-57,73-74)
+                        c_n = add(add(scl(u, ld3(at.n1)), scl(v, ld3(at.n2))), scl(w, ld3(at.n0)));
+                        if (need_uv) {
+                            hu = u * at.uv1[0] + v * at.uv2[0] + w * at.uv0[0];
+                            hv = u * at.uv1[1] + v * at.uv2[1] + w * at.uv0[1];
                         }
-                        ray = ray_from_pixel(cam, fx, fy);
-                        depth = 0; fsp = 0;
-                        if (COUNT) cnt.c[CNT_PRIMARY]++;
-                        qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
-                    } else if (state == ST_HIT) {
-                        // traceRay (src/RayHs.hs:149-154)
-                        if (tr.bobj < 0) { result = mk(0, 0, 0); step = A_RETURN; }
-                        else {
-                            const DObject &ob = sc.objects[tr.bobj];
-                            if (COUNT) cnt.c[CNT_SHADED]++;
-                            c_obj = tr.bobj;
-                            c_v = ray.d;
-                            c_p = add(ray.o, scl(tr.bt, ray.d));  // rayAt (src/Geometry.hs:27-29)
-                            double hu = 0, hv = 0;
-                            const bool need_uv = ((ob.mat_kind == 1 || ob.mat_kind == 2) && ob.cmap_kind != 0) || ob.mat_kind == 6;
-                            if (tr.btri >= 0) {
-                                const DTriAttr &at = sc.attrs[tr.btri];
-                                double u = tr.bu, v = tr.bv, w = 1 - u - v;
-                                // barycentricInterp u n1 v n2 (1-u-v) n0 (src/Mesh.hs:53-57,73-74)
-                                c_n = add(add(scl(u, ld3(at.n1)), scl(v, ld3(at.n2))), scl(w, ld3(at.n0)));
-                                hu = u * at.uv1[0] + v * at.uv2[0] + w * at.uv0[0];
-                                hv = u * at.uv1[1] + v * at.uv2[1] + w * at.uv0[1];
-                            } else {
-                                // re-derive the analytic hit from t
-                                if (tr.bprim >= 0) {
-                                    const DPlane &pl = sc.planes[tr.bprim];
-                                    c_n = ld3(pl.n);
-                                    if (need_uv) { V3 rel = sub(c_p, ld3(pl.p)); hu = dot(ld3(pl.t), rel); hv = dot(ld3(pl.b), rel); }
-                                } else {
-                                    const DSphere &s = sc.spheres[-tr.bprim - 2];
-                                    c_n = unit(sub(c_p, ld3(s.c)));
-                                    if (need_uv) { hu = kPiInv * atan(c_n.z / c_n.x); hv = kPiInv * acos(c_n.y); }  // polar, src/Geometry.hs:96
-                                }
-                            }
-                            // irradiance (src/RayHs.hs:107-147)
-                            switch (ob.mat_kind) {
-                            case 1: case 2:  // Diffuse, Plastic
-                                c_cd = color_at(ob, sc.texels, hu, hv);
-                                c_A = mk(0, 0, 0); c_li = 0;
-                                step = A_LIGHT_NEXT;
-                                break;
-                            case 0:  // Mirror
-                                spec_with_A = false; step = A_SPEC;
-                                break;
-                            case 3:  // Emmit
-                                result = ld3(ob.ce); step = A_RETURN;
-                                break;
-                            case 4: {  // Transparent: try to transmit (src/RayHs.hs:136-143)
-                                V3 refdir;
-                                if (depth != prm.max_depth && refract(c_v, c_n, 1.0, ob.ior, refdir)) {
-                                    c_cd = refdir;  // keep refDir across the exit query
-                                    ray.o = add(c_p, scl(kEps, refdir)); ray.d = refdir;  // rayEps
-                                    if (COUNT) cnt.c[CNT_REFRACT_EXIT]++;
-                                    qkind = Q_CLOSEST; state = ST_EXIT; step = A_QUERY_READY;
-                                } else { spec_with_A = false; step = A_SPEC; }
-                                break;
-                            }
-                            case 5: result = c_n; step = A_RETURN; break;           // ShowNormal
-                            default: result = mk(hu, hv, 0); step = A_RETURN; break; // ShowUV
-                            }
-                        }
-                    } else if (state == ST_SHADOW) {
-                        // accumDiffuse fold step (src/RayHs.hs:90-96)
-                        c_A = add(c_A, occluded ? mk(0, 0, 0) : c_term);
-                        c_li++;
-                        step = A_LIGHT_NEXT;
-                    } else {  // ST_EXIT: the transmitted ray's exit point (src/RayHs.hs:140-143)
-                        const DObject &ob = sc.objects[c_obj];
-                        bool have = false;
-                        if (tr.bobj >= 0) {
-                            V3 outp = add(ray.o, scl(tr.bt, ray.d));
-                            V3 outn;
-                            if (tr.btri >= 0) {
-                                const DTriAttr &at = sc.attrs[tr.btri];
-                                double u = tr.bu, v = tr.bv, w = 1 - u - v;
-                                outn = add(add(scl(u, ld3(at.n1)), scl(v, ld3(at.n2))), scl(w, ld3(at.n0)));
-                            } else {
-                                if (tr.bprim >= 0) outn = ld3(sc.planes[tr.bprim].n);
-                                else outn = unit(sub(outp, ld3(sc.spheres[-tr.bprim - 2].c)));
-                            }
-                            V3 outdir;
-                            if (refract(c_cd, neg(outn), ob.ior, 1.0, outdir)) {
-                                have = true;
-                                // suspend this irradiance call: radiance child first, specular child later
-                                V3 rf = reflect(c_v, c_n);
-                                frame_store(ws, stride, fsp, FS_KIND, (double)FR_TRANS_WAIT_RADIANCE);
-                                frame_store(ws, stride, fsp, FS_DEPTH, (double)depth);
-                                frame_store(ws, stride, fsp, FS_F, fresnel(ob.fr, dot(c_n, neg(c_v))));
-                                frame_store(ws, stride, fsp, FS_S, dot(rf, c_n));
-                                frame_store(ws, stride, fsp, FS_K, ob.one_m_r0);
-                                frame_store3(ws, stride, fsp, FS_RO, add(c_p, scl(kEps, rf)));
-                                frame_store3(ws, stride, fsp, FS_RD, rf);
-                                fsp++;
-                                ray.o = add(outp, scl(kEps, outdir)); ray.d = outdir;
-                                depth = depth + 1;
-                                if (COUNT) cnt.c[CNT_REFRACT]++;
-                                qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
-                            }
-                        }
-                        if (!have) { spec_with_A = false; step = A_SPEC; }
+                    } else if (tr.bprim >= 0) {  // re-derive the analytic hit from t
+                        const auto &pl = as_const(sc.planes)[tr.bprim];
+                        c_n = ld3(pl.n);
+                        if (need_uv) { V3 rel = sub(c_p, ld3(pl.p)); hu = dot(ld3(pl.t), rel); hv = dot(ld3(pl.b), rel); }
+                    } else {
+                        const auto &s = as_const(sc.spheres)[-tr.bprim - 2];
+                        c_n = unit(sub(c_p, ld3(s.c)));
+                        if (need_uv) polar_uv(c_n, hu, hv);  // src/Geometry.hs:96
                     }
-                } else if (step == A_LIGHT_NEXT) {
-                    const DObject &ob = sc.objects[c_obj];
-                    if (c_li < sc.n_lights) {
-                        // lightAt (src/Light.hs:12-17) + diffuse (src/Material.hs:31-33)
-                        const DLight &L = sc.lights[c_li];
-                        V3 ld, lc;
-                        if (L.kind == 0) { ld = ld3(L.v); lc = ld3(L.c); q_point = false; q_d2 = 0; q_dist = __builtin_inf(); }
-                        else {
-                            V3 dv = sub(ld3(L.v), c_p);
-                            double d = sqrt(dot(dv, dv));
-                            double den = 1.0 + d / L.radius;
-                            double falloff = 1.0 / (den * den);
-                            ld = scl(1 / d, dv);
-                            lc = scl(falloff, ld3(L.c));
-                            q_point = true; q_dist = d;
-                        }
-                        c_term = scl(hs_max(dot(ld, c_n), 0) * kPiInv, mulv(c_cd, lc));
-                        ray.o = add(c_p, scl(kEps, ld)); ray.d = ld;  // rayEps p ld
-                        if (q_point) { V3 dd = sub(ray.o, ld3(L.v)); q_d2 = dot(dd, dd); }  // sqrDist origin p (src/RayHs.hs:87)
-                        if (COUNT) cnt.c[CNT_SHADOW]++;
-                        qkind = Q_SHADOW; state = ST_SHADOW; step = A_QUERY_READY;
-                    } else if (ob.mat_kind == 1) {
-                        result = add(scl(0.2, c_cd), c_A);  // Diffuse (src/RayHs.hs:111-114)
-                        step = A_RETURN;
-                    } else { spec_with_A = true; step = A_SPEC; }  // Plastic (src/RayHs.hs:117-120)
-                } else if (step == A_SPEC) {
-                    // fresnel * specular (src/RayHs.hs:99-104,119,124,132)
-                    const DObject &ob = sc.objects[c_obj];
-                    double F = fresnel(ob.fr, dot(c_n, neg(c_v)));
-                    if (depth < prm.max_depth) {
+                    // irradiance (src/RayHs.hs:107-147)
+                    if (mat_kind == 1 || mat_kind == 2) {  // Diffuse, Plastic
+                        c_cd = ob.cmap_kind == 0 ? ld3(ob.c1) : color_at_slow(as_const(sc.objects), tr.bobj, sc.texels, hu, hv);
+                        c_A = mk(0, 0, 0); c_li = 0;
+                        step = A_LIGHT_NEXT;
+                    } else if (mat_kind == 0) {  // Mirror
+                        spec_with_A = false; step = A_SPEC;
+                    } else if (mat_kind == 3) {  // Emmit
+                        result = ld3(ob.ce); step = A_RETURN;
+                    } else if (mat_kind == 4) {  // Transparent: try to transmit (src/RayHs.hs:136-143)
+                        V3 refdir;
+                        if (depth != prm.max_depth && refract(ray.d, c_n, 1.0, ob.ior, refdir)) {
+                            c_cd = refdir;  // keep refDir across the exit query
+                            ray.o = add(c_p, scl(kEps, refdir)); ray.d = refdir;  // rayEps
+                            if (COUNT) cnt.c[CNT_REFRACT_EXIT]++;
+                            qkind = Q_CLOSEST; state = ST_EXIT; step = A_QUERY_READY;
+                        } else { spec_with_A = false; step = A_SPEC; }
+                    } else if (mat_kind == 5) { result = c_n; step = A_RETURN; }   // ShowNormal
+                    else { result = mk(hu, hv, 0); step = A_RETURN; }               // ShowUV
+                }
+            } else if (state == ST_SHADOW) {
+                // accumDiffuse fold step (src/RayHs.hs:90-96)
+                c_p = cx_load3(cx, CX_P); c_n = cx_load3(cx, CX_N); c_cd = cx_load3(cx, CX_CD);
+                c_A = add(cx_load3(cx, CX_A), occluded ? mk(0, 0, 0) : ws_load3(ws, stride, LS_TERM));
+                c_li++;
+                step = A_LIGHT_NEXT;
+            } else if (state == ST_EXIT) {
+                // the transmitted ray's exit point (src/RayHs.hs:140-143)
+                c_p = cx_load3(cx, CX_P); c_n = cx_load3(cx, CX_N); c_cd = cx_load3(cx, CX_CD);
+                const auto &ob = as_const(sc.objects)[c_obj];
+                bool have = false;
+                if (tr.bobj >= 0) {
+                    V3 outp = add(ray.o, scl(tr.bt, ray.d));
+                    V3 outn;
+                    if (tr.btri >= 0) {
+                        const DTriAttr &at = (tr.bref ? sc.attrs : sc.fattrs)[tr.btri];
+                        double u = tr.bu, v = tr.bv, w = 1 - u - v;
+                        outn = add(add(scl(u, ld3(at.n1)), scl(v, ld3(at.n2))), scl(w, ld3(at.n0)));
+                    } else if (tr.bprim >= 0) outn = ld3(as_const(sc.planes)[tr.bprim].n);
+                    else outn = unit(sub(outp, ld3(as_const(sc.spheres)[-tr.bprim - 2].c)));
+                    V3 outdir;
+                    if (refract(c_cd, neg(outn), ob.ior, 1.0, outdir)) {
+                        have = true;
+                        // suspend this irradiance call: radiance child first, specular child later
+                        V3 c_v = ws_load3(ws, stride, LS_V);
                         V3 rf = reflect(c_v, c_n);
-                        frame_store(ws, stride, fsp, FS_KIND, (double)(spec_with_A ? FR_PLASTIC : FR_MIRROR));
-                        frame_store(ws, stride, fsp, FS_DEPTH, (double)depth);
-                        frame_store(ws, stride, fsp, FS_F, F);
-                        frame_store(ws, stride, fsp, FS_S, dot(rf, c_n));
-                        if (spec_with_A) frame_store3(ws, stride, fsp, FS_A, c_A);
+                        ws_store(ws, stride, fslot(fsp, FS_KIND), (double)FR_TRANS_WAIT_RADIANCE);
+                        ws_store(ws, stride, fslot(fsp, FS_DEPTH), (double)depth);
+                        ws_store(ws, stride, fslot(fsp, FS_F), fresnel(ob.fr, dot(c_n, neg(c_v))));
+                        ws_store(ws, stride, fslot(fsp, FS_S), dot(rf, c_n));
+                        ws_store(ws, stride, fslot(fsp, FS_K), ob.one_m_r0);
+                        ws_store3(ws, stride, fslot(fsp, FS_RO), add(c_p, scl(kEps, rf)));
+                        ws_store3(ws, stride, fslot(fsp, FS_RD), rf);
                         fsp++;
-                        ray.o = add(c_p, scl(kEps, rf)); ray.d = rf;
+                        ray.o = add(outp, scl(kEps, outdir)); ray.d = outdir;
                         depth = depth + 1;
+                        if (COUNT) cnt.c[CNT_REFRACT]++;
+                        qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
+                    }
+                }
+                if (!have) { spec_with_A = false; step = A_SPEC; }
+            }
+
+            if (step == A_LIGHT_NEXT) {
+                if (c_li < sc.n_lights) {
+                    // lightAt (src/Light.hs:12-17) + diffuse (src/Material.hs:31-33)
+                    const auto &L = as_const(sc.lights)[c_li];
+                    V3 ld, lc;
+                    if (L.kind == 0) { ld = ld3(L.v); lc = ld3(L.c); q_point = false; q_d2 = 0; q_dist = __builtin_inf(); }
+                    else {
+                        V3 dv = sub(ld3(L.v), c_p);
+                        double d = sqrt(dot(dv, dv));
+                        double den = 1.0 + d / L.radius;
+                        double falloff = 1.0 / (den * den);
+                        ld = scl(1 / d, dv);
+                        lc = scl(falloff, ld3(L.c));
+                        q_point = true; q_dist = d;
+                    }
+                    // the light's diffuse term, added after the shadow query if unoccluded
+                    ws_store3(ws, stride, LS_TERM, scl(hs_max(dot(ld, c_n), 0) * kPiInv, mulv(c_cd, lc)));
+                    ray.o = add(c_p, scl(kEps, ld)); ray.d = ld;  // rayEps p ld
+                    if (q_point) { V3 dd = sub(ray.o, ld3(L.v)); q_d2 = dot(dd, dd); }  // sqrDist origin p (src/RayHs.hs:87)
+                    if (COUNT) cnt.c[CNT_SHADOW]++;
+                    // park the context of the hit being shaded while its shadow ray is traced
+                    cx_store3(cx, CX_P, c_p); cx_store3(cx, CX_N, c_n); cx_store3(cx, CX_CD, c_cd); cx_store3(cx, CX_A, c_A);
+                    qkind = Q_SHADOW; state = ST_SHADOW; step = A_QUERY_READY;
+                } else if (as_const(sc.objects)[c_obj].mat_kind == 1) {
+                    result = add(scl(0.2, c_cd), c_A);  // Diffuse (src/RayHs.hs:111-114)
+                    step = A_RETURN;
+                } else { spec_with_A = true; step = A_SPEC; }  // Plastic (src/RayHs.hs:117-120)
+            }
+            if (state == ST_EXIT && step == A_QUERY_READY) {  // park p, n, refDir across the exit query
+                cx_store3(cx, CX_P, c_p); cx_store3(cx, CX_N, c_n); cx_store3(cx, CX_CD, c_cd);
+            }
+
+            if (step == A_SPEC) {
+                // fresnel * specular (src/RayHs.hs:99-104,119,124,132)
+                const auto &ob = as_const(sc.objects)[c_obj];
+                V3 c_v = ws_load3(ws, stride, LS_V);
+                double F = fresnel(ob.fr, dot(c_n, neg(c_v)));
+                if (depth < prm.max_depth) {
+                    V3 rf = reflect(c_v, c_n);
+                    ws_store(ws, stride, fslot(fsp, FS_KIND), (double)(spec_with_A ? FR_PLASTIC : FR_MIRROR));
+                    ws_store(ws, stride, fslot(fsp, FS_DEPTH), (double)depth);
+                    ws_store(ws, stride, fslot(fsp, FS_F), F);
+                    ws_store(ws, stride, fslot(fsp, FS_S), dot(rf, c_n));
+                    if (spec_with_A) ws_store3(ws, stride, fslot(fsp, FS_A), c_A);
+                    fsp++;
+                    ray.o = add(c_p, scl(kEps, rf)); ray.d = rf;
+                    depth = depth + 1;
+                    if (COUNT) cnt.c[CNT_REFLECT]++;
+                    qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
+                } else {
+                    V3 spec = scl(F, mk(0, 0, 0));
+                    result = spec_with_A ? add(c_A, spec) : spec;
+                    step = A_RETURN;
+                }
+            }
+
+            // hand `result` to the suspended callers until one needs another ray, or the sample is done
+            while (step == A_RETURN) {
+                if (fsp == 0) {
+                    V3 c = result;
+                    if (prm.spp > 1) {
+                        V3 sum = add(ws_load3(ws, stride, LS_SUM), result);  // foldl (+) black (src/RayHs.hs:171)
+                        ws_store3(ws, stride, LS_SUM, sum);
+                        c = scl(1.0 / (double)prm.spp, sum);
+                    }
+                    sample++;
+                    if (sample < prm.spp) state = ST_NEW_SAMPLE;
+                    else {
+                        size_t o = ((size_t)lrow * (size_t)prm.width + (size_t)px) * 3;
+                        if (prm.out_format == 0) { float *f = (float *)out; f[o] = (float)c.x; f[o + 1] = (float)c.y; f[o + 2] = (float)c.z; }
+                        else if (prm.out_format == 1) { double *f = (double *)out; f[o] = c.x; f[o + 1] = c.y; f[o + 2] = c.z; }
+                        else {
+                            // toIntC (src/Image.hs:54-55): truncate (255 * min c 1), saturated to int16
+                            short *q = (short *)out;
+                            double v0 = 255 * hs_min(c.x, 1), v1 = 255 * hs_min(c.y, 1), v2 = 255 * hs_min(c.z, 1);
+                            q[o] = (short)(v0 < -32768.0 ? -32768 : (int)v0);
+                            q[o + 1] = (short)(v1 < -32768.0 ? -32768 : (int)v1);
+                            q[o + 2] = (short)(v2 < -32768.0 ? -32768 : (int)v2);
+                        }
+                        if (COUNT) cnt.c[CNT_PIXELS]++;
+                        state = ST_DONE;
+                    }
+                    step = A_NONE;
+                } else {
+                    int lv = fsp - 1;
+                    int kind = (int)ws_load(ws, stride, fslot(lv, FS_KIND));
+                    double F = ws_load(ws, stride, fslot(lv, FS_F)), S = ws_load(ws, stride, fslot(lv, FS_S));
+                    if (kind == FR_PLASTIC) {
+                        result = add(ws_load3(ws, stride, fslot(lv, FS_A)), scl(F, scl(S, result)));
+                        fsp = lv;
+                    } else if (kind == FR_MIRROR) {
+                        result = scl(F, scl(S, result));
+                        fsp = lv;
+                    } else if (kind == FR_TRANS_WAIT_RADIANCE) {
+                        ws_store3(ws, stride, fslot(lv, FS_A), result);
+                        ws_store(ws, stride, fslot(lv, FS_KIND), (double)FR_TRANS_WAIT_SPEC);
+                        ray.o = ws_load3(ws, stride, fslot(lv, FS_RO));
+                        ray.d = ws_load3(ws, stride, fslot(lv, FS_RD));
+                        depth = (int)ws_load(ws, stride, fslot(lv, FS_DEPTH)) + 1;
                         if (COUNT) cnt.c[CNT_REFLECT]++;
                         qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
                     } else {
-                        V3 spec = scl(F, mk(0, 0, 0));
-                        result = spec_with_A ? add(c_A, spec) : spec;
-                        step = A_RETURN;
-                    }
-                } else {  // A_RETURN: hand `result` to the suspended caller, or finish the sample
-                    if (fsp == 0) {
-                        sum = add(sum, result);  // foldl (+) black (src/RayHs.hs:171)
-                        sample++;
-                        if (sample < prm.spp) { state = ST_NEW_SAMPLE; step = A_DISPATCH; }
-                        else {
-                            V3 c = prm.spp == 1 ? result : scl(1.0 / (double)prm.spp, sum);
-                            size_t o = ((size_t)lrow * (size_t)prm.width + (size_t)px) * 3;
-                            if (prm.out_format == 0) { float *f = (float *)out; f[o] = (float)c.x; f[o + 1] = (float)c.y; f[o + 2] = (float)c.z; }
-                            else if (prm.out_format == 1) { double *f = (double *)out; f[o] = c.x; f[o + 1] = c.y; f[o + 2] = c.z; }
-                            else {
-                                // toIntC (src/Image.hs:54-55): truncate (255 * min c 1), saturated to int16
-                                short *q = (short *)out;
-                                double v0 = 255 * hs_min(c.x, 1), v1 = 255 * hs_min(c.y, 1), v2 = 255 * hs_min(c.z, 1);
-                                q[o] = (short)(v0 < -32768.0 ? -32768 : (int)v0);
-                                q[o + 1] = (short)(v1 < -32768.0 ? -32768 : (int)v1);
-                                q[o + 2] = (short)(v2 < -32768.0 ? -32768 : (int)v2);
-                            }
-                            if (COUNT) cnt.c[CNT_PIXELS]++;
-                            state = ST_DONE;
-                        }
-                    } else {
-                        int lv = fsp - 1;
-                        int kind = (int)frame_load(ws, stride, lv, FS_KIND);
-                        double F = frame_load(ws, stride, lv, FS_F), S = frame_load(ws, stride, lv, FS_S);
-                        if (kind == FR_PLASTIC) {
-                            result = add(frame_load3(ws, stride, lv, FS_A), scl(F, scl(S, result)));
-                            fsp = lv;
-                        } else if (kind == FR_MIRROR) {
-                            result = scl(F, scl(S, result));
-                            fsp = lv;
-                        } else if (kind == FR_TRANS_WAIT_RADIANCE) {
-                            frame_store3(ws, stride, lv, FS_A, result);
-                            frame_store(ws, stride, lv, FS_KIND, (double)FR_TRANS_WAIT_SPEC);
-                            ray.o = frame_load3(ws, stride, lv, FS_RO);
-                            ray.d = frame_load3(ws, stride, lv, FS_RD);
-                            depth = (int)frame_load(ws, stride, lv, FS_DEPTH) + 1;
-                            if (COUNT) cnt.c[CNT_REFLECT]++;
-                            qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
-                        } else {
-                            double K = frame_load(ws, stride, lv, FS_K);
-                            result = add(scl(K, frame_load3(ws, stride, lv, FS_A)), scl(F, scl(S, result)));
-                            fsp = lv;
-                        }
+                        double K = ws_load(ws, stride, fslot(lv, FS_K));
+                        result = add(scl(K, ws_load3(ws, stride, fslot(lv, FS_A))), scl(F, scl(S, result)));
+                        fsp = lv;
                     }
                 }
             }
+
+            if (state == ST_NEW_SAMPLE) {
+                // pixelCoord (src/Image.hs:31-32) + optional sample offset (src/RayHs.hs:178-188)
+                double fx = (double)px, fy = (double)yrow;
+                if (prm.spp > 1) {
+                    uint64_t pixel = (uint64_t)px + (uint64_t)prm.width * (uint64_t)yrow;
+                    fx = fx + (sample01(seed_mixed, pixel, (uint32_t)sample, 0, (uint32_t)prm.spp) - 0.5);
+                    fy = fy + (sample01(seed_mixed, pixel, (uint32_t)sample, 1, (uint32_t)prm.spp) - 0.5);
+                }
+                ray = ray_from_pixel(cam, fx, fy);
+                depth = 0; fsp = 0;
+                if (COUNT) cnt.c[CNT_PRIMARY]++;
+                qkind = Q_CLOSEST; state = ST_HIT;
+            }
         }
 
-        // ---- the single scene-query site shared by every lane of the wave
+        // ---- the single scene-query site shared by every lane of the wave.  The compiler barriers keep
+        // parked values in LDS / the workspace instead of forwarding them through registers.
+        asm volatile("" ::: "memory");
         occluded = tr.query(qkind, ray, q_point, q_d2, q_dist);
+        asm volatile("" ::: "memory");
     }
 
     if (COUNT) {
@@ -630,36 +803,41 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
 
 using namespace rayhs;
 
-#define RAYHS_DEFINE_KERNEL(NAME, EXH, COUNT)                                                                     \
-    extern "C" __global__ void __launch_bounds__(TRACE_BLOCK)                                                     \
+#ifndef RAYHS_WAVES_PER_EU
+#define RAYHS_WAVES_PER_EU 4
+#endif
+#define RAYHS_DEFINE_KERNEL(NAME, EXH, COUNT, STACKT, WPE)                                                        \
+    extern "C" __global__ void __launch_bounds__(TRACE_BLOCK, WPE)                                                \
     RAYHS_CAT(NAME, RAYHS_KERNEL_SUFFIX)(DScene sc, DCamera cam, DParams prm, void *out,                          \
                                          unsigned long long *counters, unsigned int *ticket, double *frames) {    \
-        trace_body<EXH, COUNT>(sc, cam, prm, out, counters, ticket, frames);                                      \
+        trace_body<EXH, COUNT, STACKT>(sc, cam, prm, out, counters, ticket, frames);                              \
     }
 
-RAYHS_DEFINE_KERNEL(rayhs_trace, false, false)
-RAYHS_DEFINE_KERNEL(rayhs_trace_count, false, true)
-RAYHS_DEFINE_KERNEL(rayhs_trace_exh_count, true, true)
+RAYHS_DEFINE_KERNEL(rayhs_trace, false, false, unsigned short, RAYHS_WAVES_PER_EU)       // < 65536 BVH nodes
+RAYHS_DEFINE_KERNEL(rayhs_trace_wide, false, false, unsigned int, RAYHS_WAVES_PER_EU)   // any scene
+RAYHS_DEFINE_KERNEL(rayhs_trace_count, false, true, unsigned int, 2)
+RAYHS_DEFINE_KERNEL(rayhs_trace_exh_count, true, true, unsigned int, 1)
 
 // Host-side launcher of this translation unit's kernels (called from abi.cpp).
 namespace rayhs {
+static const void *RAYHS_CAT(kernel_ptr, RAYHS_KERNEL_SUFFIX)(int variant) {
+    switch (variant) {
+    case 0: return (const void *)RAYHS_CAT(rayhs_trace, RAYHS_KERNEL_SUFFIX);
+    case 1: return (const void *)RAYHS_CAT(rayhs_trace_count, RAYHS_KERNEL_SUFFIX);
+    case 2: return (const void *)RAYHS_CAT(rayhs_trace_exh_count, RAYHS_KERNEL_SUFFIX);
+    default: return (const void *)RAYHS_CAT(rayhs_trace_wide, RAYHS_KERNEL_SUFFIX);
+    }
+}
 hipError_t RAYHS_CAT(launch_trace, RAYHS_KERNEL_SUFFIX)(int variant, int grid, size_t lds_bytes, hipStream_t stream,
                                                         const DScene &sc, const DCamera &cam, const DParams &prm, void *out,
                                                         unsigned long long *counters, unsigned int *ticket, double *frames) {
-    dim3 g((unsigned)grid), b(TRACE_BLOCK);
-    switch (variant) {
-    case 0: hipLaunchKernelGGL(RAYHS_CAT(rayhs_trace, RAYHS_KERNEL_SUFFIX), g, b, lds_bytes, stream, sc, cam, prm, out, counters, ticket, frames); break;
-    case 1: hipLaunchKernelGGL(RAYHS_CAT(rayhs_trace_count, RAYHS_KERNEL_SUFFIX), g, b, lds_bytes, stream, sc, cam, prm, out, counters, ticket, frames); break;
-    default: hipLaunchKernelGGL(RAYHS_CAT(rayhs_trace_exh_count, RAYHS_KERNEL_SUFFIX), g, b, lds_bytes, stream, sc, cam, prm, out, counters, ticket, frames); break;
-    }
-    return hipGetLastError();
+    void *args[] = {(void *)&sc, (void *)&cam, (void *)&prm, (void *)&out, (void *)&counters, (void *)&ticket, (void *)&frames};
+    return hipLaunchKernel(RAYHS_CAT(kernel_ptr, RAYHS_KERNEL_SUFFIX)(variant), dim3((unsigned)grid), dim3(TRACE_BLOCK), args, lds_bytes, stream);
 }
 int RAYHS_CAT(occupancy_trace, RAYHS_KERNEL_SUFFIX)(int variant, size_t lds_bytes) {
     int n = 0;
-    const void *f = variant == 0 ? (const void *)RAYHS_CAT(rayhs_trace, RAYHS_KERNEL_SUFFIX)
-                  : variant == 1 ? (const void *)RAYHS_CAT(rayhs_trace_count, RAYHS_KERNEL_SUFFIX)
-                                 : (const void *)RAYHS_CAT(rayhs_trace_exh_count, RAYHS_KERNEL_SUFFIX);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, TRACE_BLOCK, lds_bytes) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, RAYHS_CAT(kernel_ptr, RAYHS_KERNEL_SUFFIX)(variant), TRACE_BLOCK, lds_bytes) != hipSuccess) return 0;
     return n;
 }
+int RAYHS_CAT(stack_entry_bytes, RAYHS_KERNEL_SUFFIX)(int variant) { return variant == 0 ? 2 : 4; }
 }  // namespace rayhs

