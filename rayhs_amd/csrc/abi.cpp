@@ -185,7 +185,7 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
     std::vector<DTriAttr> fattrs;
     std::vector<int> mesh_froot((size_t)d.n_meshes, FNODE_NONE), mesh_tri_base((size_t)d.n_meshes, 0);
     std::vector<double> mesh_center(3 * (size_t)d.n_meshes, 0.0);
-    std::vector<float> mesh_fbox(6 * (size_t)d.n_meshes, 0.0f);
+    std::vector<float> mesh_fbox(12 * (size_t)d.n_meshes, 0.0f);
     int fast_depth = 0;
     for (int m = 0; m < d.n_meshes; m++) {
         std::vector<int> ids;       // triangle indices in reference DFS order
@@ -214,17 +214,33 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
         mesh_tri_base[(size_t)m] = tri_base;
         double ext = 0, ctr[3];
         for (int c = 0; c < 3; c++) { ctr[c] = 0.5 * (bvh.lo[c] + bvh.hi[c]); ext = std::max(ext, bvh.hi[c] - bvh.lo[c]); mesh_center[3 * (size_t)m + (size_t)c] = ctr[c]; }
-        // boxes are stored relative to the mesh centre, rounded outward and inflated by 2^-18 of the mesh
-        // extent: 64x the fp32 rounding error of a ray origin inside the mesh bounds (trace_kernel.hip)
+        // mesh bounds relative to the mesh centre, rounded outward and inflated by 2^-18 of the mesh extent
+        // (64x the fp32 rounding error of a ray origin inside them, trace_kernel.hip): root cull + grid frame
         const double infl = std::max(ext, 1e-300) * (1.0 / 262144.0);
-        auto quant = [&](const double *lo, const double *hi, float *flo, float *fhi) {
+        float *mf = &mesh_fbox[12 * (size_t)m];  // flo[3], fhi[3], glo[3], gstep[3]
+        for (int c = 0; c < 3; c++) {
+            mf[c] = round_down_f32((bvh.lo[c] - ctr[c]) - infl);
+            mf[3 + c] = round_up_f32((bvh.hi[c] - ctr[c]) + infl);
+            mf[6 + c] = mf[c];
+            // step: (fhi - flo) / 65535 rounded up, so that 65535 steps reach past fhi
+            mf[9 + c] = round_up_f32(((double)mf[3 + c] - (double)mf[c]) / 65535.0 * (1.0 + 1e-6));
+            if (!(mf[9 + c] > 0)) mf[9 + c] = 1e-30f;
+        }
+        // node boxes: 16-bit grid coordinates, floor/ceil plus ONE extra unit outward.  The extra unit
+        // (1.5e-5 of the extent) covers every fp32 rounding in the kernel's fused slab test.
+        auto quant = [&](const double *lo, const double *hi, uint16_t *qlo, uint16_t *qhi) {
             for (int c = 0; c < 3; c++) {
-                if (lo[c] <= hi[c]) { flo[c] = round_down_f32((lo[c] - ctr[c]) - infl); fhi[c] = round_up_f32((hi[c] - ctr[c]) + infl); }
-                else { flo[c] = INFINITY; fhi[c] = -INFINITY; }
+                if (lo[c] <= hi[c]) {
+                    double a = std::floor(((lo[c] - ctr[c]) - (double)mf[6 + c]) / (double)mf[9 + c]) - 1.0;
+                    double b = std::ceil(((hi[c] - ctr[c]) - (double)mf[6 + c]) / (double)mf[9 + c]) + 1.0;
+                    qlo[c] = (uint16_t)std::min(65535.0, std::max(0.0, a));
+                    qhi[c] = (uint16_t)std::min(65535.0, std::max(0.0, b));
+                } else { qlo[c] = 65535; qhi[c] = 0; }
             }
         };
-        quant(bvh.lo, bvh.hi, &mesh_fbox[6 * (size_t)m], &mesh_fbox[6 * (size_t)m + 3]);
-        auto child = [&](int c) { return c == FNODE_NONE ? FNODE_NONE : c >= 0 ? c + node_base : c; };
+        // inner references index the global node array; leaf references ~((first << 3) | count) index the
+        // global BVH-ordered triangle array
+        auto child = [&](int c) { return c == FNODE_NONE ? FNODE_NONE : c >= 0 ? c + node_base : ~((((~c) >> 3) + tri_base) << 3 | ((~c) & 7)); };
         for (const FNodeBuild &nb : bvh.nodes) {
             FNode fn;
             std::memset(&fn, 0, sizeof fn);
@@ -286,8 +302,10 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
                 m.lo[c] = m.root >= 0 ? d.node_lo[3 * m.root + c] : 0;
                 m.hi[c] = m.root >= 0 ? d.node_hi[3 * m.root + c] : 0;
                 m.center[c] = mesh_center[3 * (size_t)g + (size_t)c];
-                m.flo[c] = mesh_fbox[6 * (size_t)g + (size_t)c];
-                m.fhi[c] = mesh_fbox[6 * (size_t)g + 3 + (size_t)c];
+                m.flo[c] = mesh_fbox[12 * (size_t)g + (size_t)c];
+                m.fhi[c] = mesh_fbox[12 * (size_t)g + 3 + (size_t)c];
+                m.glo[c] = mesh_fbox[12 * (size_t)g + 6 + (size_t)c];
+                m.gstep[c] = mesh_fbox[12 * (size_t)g + 9 + (size_t)c];
             }
         }
     }
@@ -503,6 +521,8 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
                 stats->rays_refract_exit = c[CNT_REFRACT_EXIT]; stats->rays_shadow = c[CNT_SHADOW];
                 stats->nodes_tested = c[CNT_NODES]; stats->tris_tested = c[CNT_TRIS]; stats->prims_tested = c[CNT_PRIMS];
                 stats->shaded_hits = c[CNT_SHADED]; stats->pixels = c[CNT_PIXELS];
+                if (std::getenv("RAYHS_DEBUG_COUNTERS"))  // development: raw loop counters of a -DRAYHS_PROFILE_LOOPS build
+                    std::fprintf(stderr, "rayhs counters[10..15]: %llu %llu %llu %llu %llu %llu  kernel_ms %.3f\n", c[10], c[11], c[12], c[13], c[14], c[15], (double)ms);
             }
         }
     } while (0);

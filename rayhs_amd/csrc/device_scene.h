@@ -23,14 +23,15 @@ struct alignas(16) DNode {
 static constexpr int32_t DNODE_LEAF = (int32_t)0x80000000;
 
 // ---- fast traversal structure (bvh_build.cpp) ----
-// 64 B per node: both children's boxes in fp32, relative to the mesh centre,
-// rounded outward and inflated.  Child reference: >= 0 inner node,
-// < 0 leaf ~((first << 3) | count) into the BVH-ordered triangle array,
-// INT32_MIN = no child.
+// 32 B per node = two 16-byte requests per lane per visit (the L1 tag pipeline, not bandwidth, bounds a
+// divergent traversal: every 16 B a lane asks for costs it a cycle).  Both children's boxes are stored
+// as 16-bit coordinates on a per-mesh grid (DMesh.glo/gstep), rounded outward by one extra grid unit,
+// so that  t = q * (step * 1/d) + (glo - o) * 1/d  is one fused multiply-add per slab plane.
+// Child reference: >= 0 inner node, < 0 leaf ~((first << 3) | count) into the BVH-ordered triangle
+// array, INT32_MIN = no child.
 struct alignas(16) FNode {
-    float lo0[3], hi0[3], lo1[3], hi1[3];
+    uint16_t lo0[3], hi0[3], lo1[3], hi1[3];
     int32_t c0, c1;
-    int32_t pad[2];
 };
 static constexpr int32_t FNODE_NONE = (int32_t)0x80000000;
 
@@ -65,6 +66,7 @@ struct DMesh {
     double lo[3], hi[3];            // the reference root's box (src/KDTree.hs:84)
     double center[3];               // origin of the fp32 box coordinates
     float flo[3], fhi[3];           // bounds of the mesh in those coordinates, rounded outward and inflated
+    float glo[3], gstep[3];         // origin and step of the 16-bit grid the node boxes are stored on
 };
 struct DObject {  // Material (src/Material.hs:13-19) + ColorMap (src/ColorMap.hs:11-16) of one object
     int32_t mat_kind, cmap_kind, tex_w, tex_h;

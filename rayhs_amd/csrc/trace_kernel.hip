@@ -47,6 +47,15 @@
 #ifndef RAYHS_FP32_ROOT
 #define RAYHS_FP32_ROOT 1  // 1: conservative fp32 root cull; 0: the reference's exact fp64 root test
 #endif
+#ifndef RAYHS_SLICE_MIN
+#define RAYHS_SLICE_MIN 0   // leave the traversal loop when fewer lanes than this are still traversing (0: never early)
+#endif
+#ifndef RAYHS_REFILL_MIN
+#define RAYHS_REFILL_MIN 1  // idle lanes that trigger a pixel refill
+#endif
+#ifndef RAYHS_CHUNK
+#define RAYHS_CHUNK 64      // pixels drawn from the global ticket at a time (one 8x8 tile)
+#endif
 #ifndef RAYHS_KERNEL_SUFFIX
 #define RAYHS_KERNEL_SUFFIX fast
 #endif
@@ -189,7 +198,24 @@ enum : int { FR_PLASTIC = 0, FR_MIRROR, FR_TRANS_WAIT_RADIANCE, FR_TRANS_WAIT_SP
 // query kinds
 enum : int { Q_NONE = 0, Q_CLOSEST, Q_SHADOW };
 
-struct Counters { unsigned long long c[10]; };
+struct Counters { unsigned long long c[16]; };
+// development counters (slots 10..15, -DRAYHS_PROFILE_LOOPS): lane- and wave-level trip counts of the hot loops
+// -DRAYHS_PROFILE_TIME: the counting kernel is built like the production kernel (no work counters, same
+// occupancy) but lane 0 of every wave accumulates shader-clock cycles per phase into slots 10..15.
+#ifdef RAYHS_PROFILE_TIME
+#define TIME_DECL unsigned long long t_last_ = __builtin_amdgcn_s_memtime()
+#define TIME_ADD(slot) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); cnt.c[slot] += n_ - t_last_; t_last_ = n_; } while (0)
+constexpr bool kProfileTime = true;
+#else
+#define TIME_DECL do { } while (0)
+#define TIME_ADD(slot) do { } while (0)
+constexpr bool kProfileTime = false;
+#endif
+#ifdef RAYHS_PROFILE_LOOPS
+#define LOOP_TICK(slot) do { if (COUNT) { cnt.c[slot]++; if ((int)__lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1) cnt.c[(slot) + 1]++; } } while (0)
+#else
+#define LOOP_TICK(slot) do { } while (0)
+#endif
 
 DEV float f32_up(double v) {  // smallest float >= v (v >= 0 here)
     float f = (float)v;
@@ -209,8 +235,26 @@ struct Tracer {
     int bobj, btri, bleaf, brank;
     int bprim;  // winning plane index i, or sphere index as -(i + 2); -1 for a triangle / miss
     bool bref;  // btri indexes the reference-order arrays (hit found by the reference tree), else the BVH-order ones
+    bool occ;   // shadow query: an occluder was found
 
-    __device__ Tracer(const DScene &s, stack_ptr st, Counters &c) : sc(s), stack(st), cnt(c) {}
+    // resumable traversal state of the fast BVH (kept across time slices)
+    int t_m;               // next mesh to start once the current one is exhausted; n_meshes when none is left
+    int t_cur, t_sp;       // current inner node (FNODE_NONE = none), stack depth
+    int t_pa, t_pb;        // postponed leaves
+    int t_obj;             // scene object of the mesh being traversed
+    float t_ax, t_ay, t_az, t_bx, t_by, t_bz;  // per-plane slab coefficients of the current mesh (see qbox)
+    float t_enter;                             // shift of the traversal origin along the ray
+
+    __device__ __forceinline__ bool traversing() const {
+        return t_cur != FNODE_NONE || t_pa != FNODE_NONE || t_sp > 0 || t_m < sc.n_meshes;
+    }
+    __device__ __forceinline__ void stop_traversal() { t_cur = FNODE_NONE; t_pa = FNODE_NONE; t_pb = FNODE_NONE; t_sp = 0; t_m = sc.n_meshes; }
+
+    __device__ Tracer(const DScene &s, stack_ptr st, Counters &c) : sc(s), stack(st), cnt(c) {
+        bt = 0; bu = 0; bv = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; occ = false;
+        t_obj = 0; t_ax = t_ay = t_az = t_bx = t_by = t_bz = t_enter = 0;
+        stop_traversal();
+    }
 
     // ---- analytic primitives (src/Geometry.hs:68-96) ----
     template <class PL> __device__ __forceinline__ bool plane_t(const PL &pl, const Ray &r, double &t) {
@@ -279,7 +323,20 @@ struct Tracer {
         return take;
     }
 
-    // conservative fp32 slab test of one child box of the fast BVH; t is relative to the shifted origin
+    // slab test of one 16-bit child box: t = q * A + B per plane (A = grid step / d, B = (grid origin - o) / d),
+    // one fused multiply-add each.  Culling only: the stored boxes carry a whole grid unit of slack.
+    __device__ __forceinline__ bool qbox(const uint16_t *lo, const uint16_t *hi, float ax, float ay, float az, float bx, float by, float bz,
+                                         float limf, float &tnear) {
+        float t1 = __builtin_fmaf((float)lo[0], ax, bx), t2 = __builtin_fmaf((float)hi[0], ax, bx);
+        float t3 = __builtin_fmaf((float)lo[1], ay, by), t4 = __builtin_fmaf((float)hi[1], ay, by);
+        float t5 = __builtin_fmaf((float)lo[2], az, bz), t6 = __builtin_fmaf((float)hi[2], az, bz);
+        float tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+        float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+        tnear = tn;
+        return tf >= fmaxf(tn, 0.0f) && tn <= limf;
+    }
+
+    // conservative fp32 slab test of the mesh bounds (root cull); t is relative to the given origin
     __device__ __forceinline__ bool fbox(const float *lo, const float *hi, float ox, float oy, float oz, float ix, float iy, float iz,
                                          float limf, float &tnear) {
         float t1 = (lo[0] - ox) * ix, t2 = (hi[0] - ox) * ix;
@@ -292,14 +349,15 @@ struct Tracer {
         return tf >= fmaxf(tn, 0.0f) && tn <= limf;
     }
 
-    // One scene query for this lane.  kind == Q_CLOSEST fills the b* record
-    // (bobj = -1 on a miss); kind == Q_SHADOW returns whether any non-Emmit
-    // object occludes the light (src/RayHs.hs:74-87).
-    __device__ bool query(int kind, const Ray &r, bool point_light, double light_d2, double light_dist) {
+    // Start one scene query for this lane (kind == Q_NONE: lane does not start one).  Q_CLOSEST fills
+    // the b* record (bobj = -1 on a miss); Q_SHADOW sets `occ` if any non-Emmit object occludes the
+    // light (src/RayHs.hs:74-87).  Planes, spheres and (for the rare rays that need it) the reference
+    // tree are finished here; the fast BVH traversal is only armed and runs in slice().
+    __device__ void begin(int kind, const Ray &r, bool point_light, double light_d2) {
         const bool active = kind != Q_NONE;
         const bool shadow = kind == Q_SHADOW;
         bool occluded = false;
-        bt = __builtin_inf(); bu = 0; bv = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH;
+        if (active) { bt = __builtin_inf(); bu = 0; bv = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; }
 
         // ---- planes and spheres: wave-uniform loops, scene constants via scalar loads
         for (int i = 0; i < sc.n_planes; i++) {
@@ -323,17 +381,18 @@ struct Tracer {
                 else if (t < bt || (t == bt && s.obj < bobj)) { bt = t; bobj = s.obj; bprim = -(i + 2); }
             }
         }
-        if (sc.n_meshes == 0) return occluded;
-
-        // The reference's slab test multiplies by 1/d: with a zero direction component and a box plane
-        // through the origin it computes 0 * inf = NaN and may reject a box the ray does touch
-        // (src/KDTree.hs:39-56).  Its boxes are therefore NOT a conservative cull for such rays, and only
-        // its own tree reproduces its answer: those (rare) lanes walk the reference tree.
-        const bool by_reference = EXH || r.d.x == 0 || r.d.y == 0 || r.d.z == 0;
-        if (EXH || __ballot(active && by_reference) != 0ull)
-            occluded = meshes_reference(active && by_reference, shadow, r, point_light, light_d2, occluded);
-        if (!EXH) occluded = meshes_fast(active && !by_reference, shadow, r, point_light, light_d2, light_dist, occluded);
-        return occluded;
+        if (sc.n_meshes > 0) {
+            // The reference's slab test multiplies by 1/d: with a zero direction component and a box plane
+            // through the origin it computes 0 * inf = NaN and may reject a box the ray does touch
+            // (src/KDTree.hs:39-56).  Its boxes are therefore NOT a conservative cull for such rays, and only
+            // its own tree reproduces its answer: those (rare) lanes walk the reference tree, here and now.
+            const bool by_reference = EXH || !(fabs(r.d.x) > 1e-25) || !(fabs(r.d.y) > 1e-25) || !(fabs(r.d.z) > 1e-25);  // also keeps 1/d finite in fp32
+            if (EXH || __ballot(active && by_reference) != 0ull)
+                occluded = meshes_reference(active && by_reference, shadow, r, point_light, light_d2, occluded);
+            // arm the fast traversal: slice() starts with mesh 0
+            if (!EXH && active && !by_reference && !(shadow && occluded)) t_m = 0;
+        }
+        if (active) occ = occluded;
     }
 
     // ---- the reference's own tree, both children always (src/KDTree.hs:96-115)
@@ -379,87 +438,105 @@ struct Tracer {
         return occluded;
     }
 
-    // ---- fast BVH: fp32 conservative boxes, fp64 triangle tests
-    __device__ __forceinline__ bool meshes_fast(bool active, bool shadow, const Ray &r, bool point_light, double light_d2, double light_dist, bool occluded) {
+    // ---- fast BVH: fp32 conservative boxes, fp64 triangle tests, as a resumable time slice.
+    // A wave's query round would otherwise last as long as its slowest ray.  Instead the loop is left as
+    // soon as fewer than RAYHS_SLICE_MIN lanes are still traversing while some other lane could do useful
+    // work (shade, start its next ray, fetch a pixel); the traversal state above survives and the
+    // remaining lanes resume in the next slice together with the newly started rays.
+    __device__ void slice(bool shadow, const Ray &r, bool point_light, double light_d2, double light_dist, bool useful_when_free) {
+        if (EXH) return;
         // reciprocal direction in fp32 (1 ulp): every use below is a conservative cull, never a result
         const float ix = __builtin_amdgcn_rcpf((float)r.d.x), iy = __builtin_amdgcn_rcpf((float)r.d.y), iz = __builtin_amdgcn_rcpf((float)r.d.z);
-        for (int m = 0; m < sc.n_meshes; m++) {
-            const auto &me = as_const(sc.meshes)[m];
-            bool go = active && me.froot != FNODE_NONE && !(shadow && (occluded || !me.occluder));
-            const double lim = shadow ? light_dist : bt;
-            // root cull in mesh-centred fp32.  The origin may be far from the mesh, so its rounding error
-            // (2^-24 of its distance) is added to the box as an explicit margin.
-            const float cxo = (float)(r.o.x - me.center[0]), cyo = (float)(r.o.y - me.center[1]), czo = (float)(r.o.z - me.center[2]);
-            const float mg = 4.76837158e-7f * fmaxf(fmaxf(fabsf(cxo), fabsf(cyo)), fabsf(czo));  // 2^-21 * max |o - c|
-            float tn_root;
-            {
+        float limf = f32_up((shadow ? light_dist : bt) - (double)t_enter);
+        TIME_DECL;
+        while (true) {
+            // start the next mesh for lanes that have exhausted the current one
+            while (t_cur == FNODE_NONE && t_pa == FNODE_NONE && t_sp == 0 && t_m < sc.n_meshes) {
+                const auto &me = as_const(sc.meshes)[t_m];
+                t_m++;
+                if (me.froot == FNODE_NONE || (shadow && !me.occluder)) continue;
+                const double lim = shadow ? light_dist : bt;
+                // root cull in mesh-centred fp32.  The origin may be far from the mesh, so its rounding error
+                // (2^-24 of its distance) is added to the box as an explicit margin.
+                const float cxo = (float)(r.o.x - me.center[0]), cyo = (float)(r.o.y - me.center[1]), czo = (float)(r.o.z - me.center[2]);
+                const float mg = 4.76837158e-7f * fmaxf(fmaxf(fabsf(cxo), fabsf(cyo)), fabsf(czo));  // 2^-21 * max |o - c|
                 float lo[3] = {me.flo[0] - mg, me.flo[1] - mg, me.flo[2] - mg};
                 float hi[3] = {me.fhi[0] + mg, me.fhi[1] + mg, me.fhi[2] + mg};
-                if (COUNT && go) cnt.c[CNT_NODES]++;
-                go = go && fbox(lo, hi, cxo, cyo, czo, ix, iy, iz, f32_up(lim), tn_root);
+                float tn_root;
+                if (COUNT) cnt.c[CNT_NODES]++;
+                if (!fbox(lo, hi, cxo, cyo, czo, ix, iy, iz, f32_up(lim), tn_root)) continue;
+                // shift the origin to (just before) the entry point, so that its fp32 rounding error inside the
+                // traversal (2^-24 of the mesh size) is far inside the 2^-18 inflation of the boxes
+                t_enter = tn_root > 0 ? tn_root * 0.99999905f : 0.0f;
+                const double te = (double)t_enter;
+                const float sx = (float)((r.o.x + te * r.d.x) - me.center[0]);
+                const float sy = (float)((r.o.y + te * r.d.y) - me.center[1]);
+                const float sz = (float)((r.o.z + te * r.d.z) - me.center[2]);
+                t_ax = me.gstep[0] * ix; t_ay = me.gstep[1] * iy; t_az = me.gstep[2] * iz;
+                t_bx = (me.glo[0] - sx) * ix; t_by = (me.glo[1] - sy) * iy; t_bz = (me.glo[2] - sz) * iz;
+                limf = f32_up(lim - te);
+                t_obj = me.obj;
+                t_cur = me.froot;
             }
-            // shift the origin to (just before) the entry point, so that its fp32 rounding error inside the
-            // traversal (2^-24 of the mesh size) is far inside the 2^-18 inflation of the boxes
-            const double t_enter = go && tn_root > 0 ? (double)(tn_root * 0.99999905f) : 0.0;
-            const float ox = (float)((r.o.x + t_enter * r.d.x) - me.center[0]);
-            const float oy = (float)((r.o.y + t_enter * r.d.y) - me.center[1]);
-            const float oz = (float)((r.o.z + t_enter * r.d.z) - me.center[2]);
-            float limf = f32_up(lim - t_enter);
-            int cur = go ? me.froot : FNODE_NONE;
-            int sp = 0;
-            int pend_a = FNODE_NONE, pend_b = FNODE_NONE;
-            while (true) {
-                // phase 1: walk inner nodes until this lane holds a leaf (or runs out of nodes)
-                while (pend_a == FNODE_NONE) {
-                    if (cur == FNODE_NONE) {
-                        if (sp == 0) break;
-                        sp--;
-                        cur = (int)stack[sp * TRACE_BLOCK];
-                    }
-                    const FNode nd = sc.fnodes[cur];
-                    float tn0, tn1;
-                    bool h0 = nd.c0 != FNODE_NONE && fbox(nd.lo0, nd.hi0, ox, oy, oz, ix, iy, iz, limf, tn0);
-                    bool h1 = nd.c1 != FNODE_NONE && fbox(nd.lo1, nd.hi1, ox, oy, oz, ix, iy, iz, limf, tn1);
-                    if (COUNT) cnt.c[CNT_NODES] += (nd.c0 != FNODE_NONE) + (nd.c1 != FNODE_NONE);
-                    const bool l0 = h0 && nd.c0 < 0, l1 = h1 && nd.c1 < 0;  // hit leaves
-                    const bool i0 = h0 && nd.c0 >= 0, i1 = h1 && nd.c1 >= 0;  // hit inner children
-                    if (l0 && l1) {  // nearer leaf first
-                        bool near0 = tn0 <= tn1;
-                        pend_a = near0 ? nd.c0 : nd.c1;
-                        pend_b = near0 ? nd.c1 : nd.c0;
-                    } else if (l0) pend_a = nd.c0;
-                    else if (l1) pend_a = nd.c1;
-                    int next = FNODE_NONE;
-                    if (i0 && i1) {
-                        bool near0 = tn0 <= tn1;
-                        next = near0 ? nd.c0 : nd.c1;
-                        stack[sp * TRACE_BLOCK] = (StackT)(near0 ? nd.c1 : nd.c0);
-                        sp++;
-                    } else if (i0) next = nd.c0;
-                    else if (i1) next = nd.c1;
-                    cur = next;
-                }
-                if (pend_a == FNODE_NONE) break;
-                // phase 2: the postponed leaf, with the reference's fp64 triangle test on the ORIGINAL ray
-                {
-                    const int ref = ~pend_a;
-                    const int first = me.tri_base + (ref >> 3), n = ref & 7;
-                    for (int k = first; k < first + n; k++) {
-                        const DTri tr = sc.ftris[k];
-                        if (COUNT) cnt.c[CNT_TRIS]++;
-                        double t, u, v;
-                        if (tri_test(tr, r, t, u, v)) {
-                            if (shadow) occluded = occluded || in_front(r, t, point_light, light_d2);
-                            else if (offer(t, u, v, me.obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - t_enter); }
-                        }
-                    }
-                    pend_a = pend_b;
-                    pend_b = FNODE_NONE;
-                }
-                if (shadow && occluded) break;
+            TIME_ADD(12);
+            // phase 1: walk inner nodes until this lane holds a leaf (or runs out of nodes).  The body is
+            // branch-free apart from the stack push/pop: the whole 32-byte node is requested at once (one
+            // memory round trip per visit) and both child boxes are always tested.
+            while (t_cur != FNODE_NONE && t_pa == FNODE_NONE) {
+                LOOP_TICK(10);
+                const FNode nd = sc.fnodes[t_cur];
+                float tn0, tn1;
+                const bool h0 = qbox(nd.lo0, nd.hi0, t_ax, t_ay, t_az, t_bx, t_by, t_bz, limf, tn0) & (nd.c0 != FNODE_NONE);
+                const bool h1 = qbox(nd.lo1, nd.hi1, t_ax, t_ay, t_az, t_bx, t_by, t_bz, limf, tn1) & (nd.c1 != FNODE_NONE);
+                if (COUNT) cnt.c[CNT_NODES] += (nd.c0 != FNODE_NONE) + (nd.c1 != FNODE_NONE);
+                const bool near0 = tn0 <= tn1;
+                const bool l0 = h0 & (nd.c0 < 0), l1 = h1 & (nd.c1 < 0);    // hit leaves
+                const bool i0 = h0 & (nd.c0 >= 0), i1 = h1 & (nd.c1 >= 0);  // hit inner children
+                // leaves are postponed, nearer one first
+                const int la = (l0 & l1) ? (near0 ? nd.c0 : nd.c1) : (l0 ? nd.c0 : nd.c1);
+                t_pa = (l0 | l1) ? la : FNODE_NONE;
+                t_pb = (l0 & l1) ? (near0 ? nd.c1 : nd.c0) : FNODE_NONE;
+                // inner children: descend into the nearer, push the other.  The push is an unconditional LDS
+                // write to the top-of-stack slot (kept only when sp advances) and the pop an unconditional read,
+                // so the loop body has no branches at all.
+                const bool both = i0 & i1, any_inner = i0 | i1, any_leaf = l0 | l1;
+                const int ia = both ? (near0 ? nd.c0 : nd.c1) : (i0 ? nd.c0 : nd.c1);
+                stack[t_sp * TRACE_BLOCK] = (StackT)(near0 ? nd.c1 : nd.c0);
+                const int top = t_sp > 0 ? t_sp - 1 : 0;
+                const int popped = (int)stack[top * TRACE_BLOCK];
+                const bool pop = !any_inner & !any_leaf & (t_sp > 0);
+                t_cur = any_inner ? ia : (pop ? popped : FNODE_NONE);
+                t_sp = t_sp + (both ? 1 : 0) - (pop ? 1 : 0);
             }
+            TIME_ADD(13);
+            // phase 2: the postponed leaf, with the reference's fp64 triangle test on the ORIGINAL ray
+            if (t_pa != FNODE_NONE) {
+                LOOP_TICK(12);
+                const int ref = ~t_pa;
+                const int first = ref >> 3, n = ref & 7;  // leaf references index the BVH-ordered arrays directly
+                for (int k = first; k < first + n; k++) {
+                    const DTri tr = sc.ftris[k];
+                    if (COUNT) cnt.c[CNT_TRIS]++;
+                    double t, u, v;
+                    if (tri_test(tr, r, t, u, v)) {
+                        if (shadow) occ = occ || in_front(r, t, point_light, light_d2);
+                        else if (offer(t, u, v, t_obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - (double)t_enter); }
+                    }
+                }
+                t_pa = t_pb;
+                t_pb = FNODE_NONE;
+                if (shadow && occ) stop_traversal();  // any occluder settles a shadow query
+            }
+            if (t_pa == FNODE_NONE && t_cur == FNODE_NONE && t_sp > 0) {
+                t_sp--;
+                t_cur = (int)stack[t_sp * TRACE_BLOCK];
+            }
+            TIME_ADD(14);
+            // leave when done, or when too few lanes traverse while others could work
+            const unsigned long long trav = __ballot(traversing());
+            if (trav == 0ull) break;
+            if (__popcll(trav) < RAYHS_SLICE_MIN && __ballot(!traversing() && useful_when_free) != 0ull) break;
         }
-        return occluded;
     }
 };
 
@@ -485,7 +562,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     const int lane = tid & 63;
     const int gtid = blockIdx.x * TRACE_BLOCK + tid;
     Counters cnt;
-    for (int i = 0; i < 10; i++) cnt.c[i] = 0;
+    for (int i = 0; i < 16; i++) cnt.c[i] = 0;
     lds_dptr cx = (lds_dptr)lds + tid;                                                  // context column
     typedef StackT __attribute__((address_space(3))) *stack_ptr;
     stack_ptr stk = (stack_ptr)((lds_dptr)lds + CTX_SLOTS * TRACE_BLOCK) + tid;          // stack column
@@ -508,17 +585,12 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     // A wave draws chunks of kChunk items from the global ticket into a wave-local pool and hands them to
     // its idle lanes, so a lane that finishes its pixel gets the next one at once instead of waiting for
     // the slowest pixel of a tile.  A fresh wave still starts on one whole, coherent tile.
-#ifndef RAYHS_REFILL_MIN
-#define RAYHS_REFILL_MIN 1
-#endif
-#ifndef RAYHS_CHUNK
-#define RAYHS_CHUNK 64
-#endif
     constexpr unsigned kChunk = RAYHS_CHUNK;
     const unsigned total_items = (unsigned)prm.n_tiles * 64u;
     unsigned pool_next = 0, pool_end = 0;
     bool exhausted = false;
 
+    TIME_DECL;
     while (true) {
         unsigned long long idle = __ballot(state == ST_DONE);
         if (__popcll(idle) < RAYHS_REFILL_MIN) idle = 0ull;
@@ -558,8 +630,12 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         // ---- advance: consume the last query's answer, run shading up to the next query.
         // Straight-line sections (hit / shadow / exit -> lights -> specular -> return -> next sample)
         // keep the live ranges short; everything declared in this block dies before the query below.
-        qkind = Q_NONE;
-        if (state != ST_DONE) {
+        // Lanes whose ray is still in flight keep their state; the others consume their answer.
+        const bool was_traversing = tr.traversing();
+        if (!was_traversing) qkind = Q_NONE;
+        occluded = tr.occ;
+        if (state != ST_DONE && !was_traversing) {
+            LOOP_TICK(14);
             V3 result = mk(0, 0, 0);
             V3 c_p = mk(0, 0, 0), c_n = mk(0, 0, 0), c_cd = mk(0, 0, 0), c_A = mk(0, 0, 0);
             enum : int { A_NONE, A_LIGHT_NEXT, A_SPEC, A_RETURN, A_QUERY_READY };
@@ -786,13 +862,18 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         // ---- the single scene-query site shared by every lane of the wave.  The compiler barriers keep
         // parked values in LDS / the workspace instead of forwarding them through registers.
         asm volatile("" ::: "memory");
-        occluded = tr.query(qkind, ray, q_point, q_d2, q_dist);
+        TIME_ADD(10);
+        tr.begin(was_traversing ? Q_NONE : qkind, ray, q_point, q_d2);
+        TIME_ADD(11);
+        tr.slice(qkind == Q_SHADOW, ray, q_point, q_d2, q_dist, state != ST_DONE || !exhausted);
+        TIME_ADD(15);
         asm volatile("" ::: "memory");
     }
 
-    if (COUNT) {
-        for (int i = 0; i < 10; i++) {
+    if ((COUNT || kProfileTime) && counters != nullptr) {
+        for (int i = 0; i < 16; i++) {
             unsigned long long v = cnt.c[i];
+            if (kProfileTime && i >= 10 && lane != 0) v = 0;  // per-wave times: lane 0 only
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
             if (lane == 0 && v) atomicAdd(&counters[i], v);
         }
@@ -815,7 +896,11 @@ using namespace rayhs;
 
 RAYHS_DEFINE_KERNEL(rayhs_trace, false, false, unsigned short, RAYHS_WAVES_PER_EU)       // < 65536 BVH nodes
 RAYHS_DEFINE_KERNEL(rayhs_trace_wide, false, false, unsigned int, RAYHS_WAVES_PER_EU)   // any scene
+#ifdef RAYHS_PROFILE_TIME
+RAYHS_DEFINE_KERNEL(rayhs_trace_count, false, false, unsigned short, RAYHS_WAVES_PER_EU)
+#else
 RAYHS_DEFINE_KERNEL(rayhs_trace_count, false, true, unsigned int, 2)
+#endif
 RAYHS_DEFINE_KERNEL(rayhs_trace_exh_count, true, true, unsigned int, 1)
 
 // Host-side launcher of this translation unit's kernels (called from abi.cpp).
@@ -839,5 +924,9 @@ int RAYHS_CAT(occupancy_trace, RAYHS_KERNEL_SUFFIX)(int variant, size_t lds_byte
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, RAYHS_CAT(kernel_ptr, RAYHS_KERNEL_SUFFIX)(variant), TRACE_BLOCK, lds_bytes) != hipSuccess) return 0;
     return n;
 }
+#ifdef RAYHS_PROFILE_TIME
+int RAYHS_CAT(stack_entry_bytes, RAYHS_KERNEL_SUFFIX)(int variant) { return variant <= 1 ? 2 : 4; }
+#else
 int RAYHS_CAT(stack_entry_bytes, RAYHS_KERNEL_SUFFIX)(int variant) { return variant == 0 ? 2 : 4; }
+#endif
 }  // namespace rayhs
