@@ -148,6 +148,7 @@ def main():
     torch.cuda.synchronize()
     names = ["rays_primary", "rays_reflect", "rays_refract", "rays_refract_exit", "rays_shadow", "nodes_tested", "tris_tested",
              "prims_tested", "shaded_hits", "pixels"]
+    counters[9] //= spp  # the kernel counts finished samples; pixels = samples / spp
     mine = dict(zip(names, counters[:10].tolist()))
     total = counters.clone()
     if world > 1:

@@ -18,9 +18,11 @@
 
 namespace rayhs {
 hipError_t launch_trace_fast(int variant, int grid, size_t lds_bytes, hipStream_t stream, const DScene &sc, const DCamera &cam,
-                             const DParams &prm, void *out, unsigned long long *counters, unsigned int *ticket, double *frames);
+                             const DParams &prm, void *out, unsigned long long *counters, unsigned long long *ticket, double *frames);
+hipError_t launch_resolve_fast(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format);
+hipError_t launch_resolve_exact(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format);
 hipError_t launch_trace_exact(int variant, int grid, size_t lds_bytes, hipStream_t stream, const DScene &sc, const DCamera &cam,
-                              const DParams &prm, void *out, unsigned long long *counters, unsigned int *ticket, double *frames);
+                              const DParams &prm, void *out, unsigned long long *counters, unsigned long long *ticket, double *frames);
 int occupancy_trace_fast(int variant, size_t lds_bytes);
 int occupancy_trace_exact(int variant, size_t lds_bytes);
 int stack_entry_bytes_fast(int variant);
@@ -57,7 +59,9 @@ struct rayhs_scene {
     // launch workspace (grow-only; steady-state renders allocate nothing)
     mutable double *frames = nullptr;
     mutable size_t frames_bytes = 0;
-    mutable unsigned int *tickets = nullptr;
+    mutable unsigned long long *tickets = nullptr;
+    mutable double *sbuf = nullptr;  // per-sample radiance of the frame in flight (spp > 1)
+    mutable size_t sbuf_bytes = 0;
     mutable unsigned next_ticket = 0;
     mutable unsigned long long *counters = nullptr;
     mutable int grid_cache[2][4][2] = {{{0}}};  // [exact][variant] -> {lds_bytes, blocks per CU}
@@ -354,8 +358,8 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
     s->d.n_tris = d.n_tris;
     s->d.n_fnodes = (int)fnodes.size();
     void *p = nullptr;
-    if (hipMalloc(&p, sizeof(unsigned int) * kTicketSlots) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(tickets) failed"));
-    s->tickets = (unsigned int *)p;
+    if (hipMalloc(&p, sizeof(unsigned long long) * kTicketSlots) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(tickets) failed"));
+    s->tickets = (unsigned long long *)p;
     if (hipMalloc(&p, sizeof(unsigned long long) * CNT_SLOTS) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(counters) failed"));
     s->counters = (unsigned long long *)p;
     *out = s;
@@ -367,6 +371,7 @@ extern "C" void rayhs_scene_destroy(rayhs_scene *s) {
     (void)hipSetDevice(s->device);
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->frames) (void)hipFree(s->frames);
+    if (s->sbuf) (void)hipFree(s->sbuf);
     if (s->tickets) (void)hipFree(s->tickets);
     if (s->counters) (void)hipFree(s->counters);
     delete s;
@@ -460,6 +465,15 @@ static int ensure_workspace(const rayhs_scene *s, const DParams &dp) {
         HIP_TRY(hipMalloc(&p, need));
         s->frames = (double *)p; s->frames_bytes = need;
     }
+    // spp > 1: one radiance triple per (pixel, sample), folded in sample order by rayhs_resolve
+    size_t sneed = dp.spp > 1 ? (size_t)dp.n_rows * (size_t)dp.width * (size_t)dp.spp * 3 * sizeof(double) : 0;
+    if (sneed > s->sbuf_bytes) {
+        if (s->sbuf) HIP_TRY(hipFree(s->sbuf));
+        s->sbuf = nullptr; s->sbuf_bytes = 0;
+        void *p = nullptr;
+        HIP_TRY(hipMalloc(&p, sneed));
+        s->sbuf = (double *)p; s->sbuf_bytes = sneed;
+    }
     return RAYHS_OK;
 }
 
@@ -473,12 +487,18 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
     if (dp.n_tiles == 0) return RAYHS_OK;
     HIP_TRY(hipSetDevice(s->device));
     if ((rc = ensure_workspace(s, dp))) return rc;
-    unsigned int *ticket = s->tickets + (s->next_ticket++ % kTicketSlots);
-    HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned int), st));
+    unsigned long long *ticket = s->tickets + (s->next_ticket++ % kTicketSlots);
+    HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), st));
+    dp.sbuf = dp.spp > 1 ? s->sbuf : nullptr;
     if (e0) HIP_TRY(hipEventRecord(e0, st));
     hipError_t e = exact ? launch_trace_exact(variant, grid, lds, st, s->d, dc, dp, d_out, (unsigned long long *)d_counters, ticket, s->frames)
                          : launch_trace_fast(variant, grid, lds, st, s->d, dc, dp, d_out, (unsigned long long *)d_counters, ticket, s->frames);
     if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "trace kernel launch failed: %s", hipGetErrorString(e));
+    if (dp.spp > 1) {
+        e = exact ? launch_resolve_exact(st, s->sbuf, d_out, dp.n_rows * dp.width, dp.spp, dp.out_format)
+                  : launch_resolve_fast(st, s->sbuf, d_out, dp.n_rows * dp.width, dp.spp, dp.out_format);
+        if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "resolve kernel launch failed: %s", hipGetErrorString(e));
+    }
     if (e1) HIP_TRY(hipEventRecord(e1, st));
     return RAYHS_OK;
 }
@@ -520,9 +540,9 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
                 stats->rays_primary = c[CNT_PRIMARY]; stats->rays_reflect = c[CNT_REFLECT]; stats->rays_refract = c[CNT_REFRACT];
                 stats->rays_refract_exit = c[CNT_REFRACT_EXIT]; stats->rays_shadow = c[CNT_SHADOW];
                 stats->nodes_tested = c[CNT_NODES]; stats->tris_tested = c[CNT_TRIS]; stats->prims_tested = c[CNT_PRIMS];
-                stats->shaded_hits = c[CNT_SHADED]; stats->pixels = c[CNT_PIXELS];
+                stats->shaded_hits = c[CNT_SHADED]; stats->pixels = c[CNT_PIXELS] / (unsigned long long)std::max(p->spp, 1);  // the kernel counts samples
                 if (std::getenv("RAYHS_DEBUG_COUNTERS"))  // development: raw loop counters of a -DRAYHS_PROFILE_LOOPS build
-                    std::fprintf(stderr, "rayhs counters[10..15]: %llu %llu %llu %llu %llu %llu  kernel_ms %.3f\n", c[10], c[11], c[12], c[13], c[14], c[15], (double)ms);
+                    std::fprintf(stderr, "rayhs span_ticks %llu counters[6..15]: %llu %llu | %llu %llu | %llu %llu %llu %llu %llu %llu  kernel_ms %.3f\n", c[5] - ~c[4], c[6], c[7], c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], (double)ms);
             }
         }
     } while (0);

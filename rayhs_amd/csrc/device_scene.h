@@ -119,6 +119,7 @@ struct DParams {
     int32_t tiles_x, n_tiles;         // 8x8-pixel tiles over (width x n_rows)
     int32_t stack_cap;                // per-lane LDS stack entries
     int32_t frame_stride;             // threads in the grid (workspace stride)
+    double *sbuf;                     // spp > 1: per-sample radiance, 3 doubles per (pixel, sample)
 };
 
 // counters[] slots
@@ -127,7 +128,7 @@ enum { CNT_PRIMARY = 0, CNT_REFLECT, CNT_REFRACT, CNT_REFRACT_EXIT, CNT_SHADOW, 
 
 static constexpr int TRACE_BLOCK = 256;     // threads per workgroup (4 waves)
 static constexpr int FRAME_SLOTS = 14;      // doubles per continuation frame
-static constexpr int LANE_SLOTS = 9;        // per-lane doubles kept in the global workspace besides frames (view dir, sample sum, light term)
+static constexpr int LANE_SLOTS = 6;        // per-lane doubles kept in the global workspace besides frames (view dir, light term)
 static constexpr int CTX_SLOTS = 12;        // per-lane doubles parked in LDS across a shadow / exit query (p, n, cd, A)
 
 }  // namespace rayhs

@@ -166,6 +166,21 @@ DEV double sample01(uint64_t seed_mixed, uint64_t pixel, uint32_t sample, uint32
     return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// final colour of a pixel in the caller's format
+DEV void store_pixel(void *out, int out_format, size_t pix, V3 c) {
+    const size_t o = pix * 3;
+    if (out_format == 0) { float *f = (float *)out; f[o] = (float)c.x; f[o + 1] = (float)c.y; f[o + 2] = (float)c.z; }
+    else if (out_format == 1) { double *f = (double *)out; f[o] = c.x; f[o + 1] = c.y; f[o + 2] = c.z; }
+    else {
+        // toIntC (src/Image.hs:54-55): truncate (255 * min c 1), saturated to int16
+        short *q = (short *)out;
+        double v0 = 255 * hs_min(c.x, 1), v1 = 255 * hs_min(c.y, 1), v2 = 255 * hs_min(c.z, 1);
+        q[o] = (short)(v0 < -32768.0 ? -32768 : (int)v0);
+        q[o + 1] = (short)(v1 < -32768.0 ? -32768 : (int)v1);
+        q[o + 2] = (short)(v2 < -32768.0 ? -32768 : (int)v2);
+    }
+}
+
 // rare paths kept out of line so that their temporaries do not inflate the kernel's register budget
 static __device__ __attribute__((noinline)) void polar_uv(V3 n, double &u, double &v) {  // polar, src/Geometry.hs:96
     u = kPiInv * atan(n.z / n.x);
@@ -541,7 +556,7 @@ struct Tracer {
 };
 
 // ---- global per-lane workspace: LANE_SLOTS lane slots, then FRAME_SLOTS per continuation level ----
-enum : int { LS_V = 0, LS_SUM = 3, LS_TERM = 6 };
+enum : int { LS_V = 0, LS_TERM = 3 };
 enum : int { FS_KIND = 0, FS_DEPTH = 1, FS_F = 2, FS_S = 3, FS_K = 4, FS_A = 5, FS_RO = 8, FS_RD = 11 };
 DEV void ws_store(double *ws, int stride, int slot, double v) { ws[(size_t)slot * (size_t)stride] = v; }
 DEV double ws_load(const double *ws, int stride, int slot) { return ws[(size_t)slot * (size_t)stride]; }
@@ -556,7 +571,7 @@ DEV V3 cx_load3(lds_dptr cx, int slot) { return mk(cx[slot * TRACE_BLOCK], cx[(s
 
 template <bool EXH, bool COUNT, typename StackT>
 static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DParams &prm, void *out,
-                                  unsigned long long *counters, unsigned int *ticket, double *frames) {
+                                  unsigned long long *counters, unsigned long long *ticket, double *frames) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -581,34 +596,46 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     int c_obj = 0, c_li = 0;
     bool occluded = false;
 
-    // Work items are pixel slots in 8x8-tile order (item >> 6 = tile, item & 63 = position in the tile).
-    // A wave draws chunks of kChunk items from the global ticket into a wave-local pool and hands them to
-    // its idle lanes, so a lane that finishes its pixel gets the next one at once instead of waiting for
-    // the slowest pixel of a tile.  A fresh wave still starts on one whole, coherent tile.
+    // Work items are (pixel, sample) pairs: item / spp is a pixel slot in 8x8-tile order (slot >> 6 = tile,
+    // slot & 63 = position in the tile), item % spp the sample.  A wave draws chunks of kChunk items from
+    // the global ticket into a wave-local pool and hands them to its idle lanes, so a lane that finishes a
+    // sample gets the next one at once.  (Per-pixel items left the frame waiting on single lanes that
+    // held an expensive pixel: 16 samples in sequence.)  With spp > 1 every sample's radiance goes to a
+    // sample buffer and rayhs_resolve adds them up in sample order, as the reference's fold does.
     constexpr unsigned kChunk = RAYHS_CHUNK;
-    const unsigned total_items = (unsigned)prm.n_tiles * 64u;
-    unsigned pool_next = 0, pool_end = 0;
+    const unsigned long long total_items = (unsigned long long)prm.n_tiles * 64ull * (unsigned long long)prm.spp;
+    unsigned long long pool_next = 0, pool_end = 0;
     bool exhausted = false;
 
     TIME_DECL;
+#ifdef RAYHS_PROFILE_TIME
+    const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime(), mt0_ = __builtin_amdgcn_s_memtime();
+#endif
     while (true) {
         unsigned long long idle = __ballot(state == ST_DONE);
         if (__popcll(idle) < RAYHS_REFILL_MIN) idle = 0ull;
         while (idle != 0ull && !exhausted) {  // wave-uniform
             if (pool_next == pool_end) {
-                unsigned c = 0;
-                if (lane == 0) c = atomicAdd(ticket, kChunk);
-                c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+                unsigned long long c = 0;
+                if (lane == 0) c = atomicAdd(ticket, (unsigned long long)kChunk);
+                c = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(c >> 32)) << 32) |
+                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)c);
                 pool_next = c;
+#ifdef RAYHS_PROFILE_TIME
+                if (c < total_items) cnt.c[7]++;  // chunks this wave obtained (lane-0 value is reduced)
+                if (c < total_items && cnt.c[6] == 0) cnt.c[6] = 1;  // waves that obtained any work
+#endif
                 pool_end = c + kChunk < total_items ? c + kChunk : total_items;
                 if (c >= total_items) { exhausted = true; break; }
             }
-            const unsigned avail = pool_end - pool_next;
+            const unsigned avail = (unsigned)(pool_end - pool_next);
             const unsigned rank = (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
             const bool take = ((idle >> lane) & 1ull) && rank < avail;
             if (take) {
-                const unsigned item = pool_next + rank;
-                const int tile = (int)(item >> 6), within = (int)(item & 63u);
+                const unsigned long long item = pool_next + rank;
+                const unsigned slot = (unsigned)(item / (unsigned)prm.spp);
+                sample = (int)(item - (unsigned long long)slot * (unsigned)prm.spp);
+                const int tile = (int)(slot >> 6), within = (int)(slot & 63u);
                 const int ty = tile / prm.tiles_x, tx = tile - ty * prm.tiles_x;
                 px = tx * 8 + (within & 7);
                 lrow = ty * 8 + (within >> 3);
@@ -616,13 +643,11 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                     // local row -> image row (stripe interleave, include/rayhs.h)
                     int s_local = lrow / prm.stripe_rows, in_stripe = lrow - s_local * prm.stripe_rows;
                     yrow = prm.row0 + (s_local * prm.stripe_count + prm.stripe_rank) * prm.stripe_rows + in_stripe;
-                    sample = 0;
-                    if (prm.spp > 1) ws_store3(ws, stride, LS_SUM, mk(0, 0, 0));
                     state = ST_NEW_SAMPLE;
                 }
             }
             const unsigned long long took = __ballot(take);
-            pool_next += (unsigned)__popcll(took);
+            pool_next += (unsigned long long)__popcll(took);
             idle &= ~took;
         }
         if (exhausted && __ballot(state != ST_DONE) == 0ull) break;
@@ -794,29 +819,16 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
             // hand `result` to the suspended callers until one needs another ray, or the sample is done
             while (step == A_RETURN) {
                 if (fsp == 0) {
-                    V3 c = result;
+                    const size_t pix = (size_t)lrow * (size_t)prm.width + (size_t)px;
                     if (prm.spp > 1) {
-                        V3 sum = add(ws_load3(ws, stride, LS_SUM), result);  // foldl (+) black (src/RayHs.hs:171)
-                        ws_store3(ws, stride, LS_SUM, sum);
-                        c = scl(1.0 / (double)prm.spp, sum);
+                        // one sample of distributedTracePixel (src/RayHs.hs:173-183); rayhs_resolve folds them in order
+                        double *sb = prm.sbuf + (pix * (size_t)prm.spp + (size_t)sample) * 3;
+                        sb[0] = result.x; sb[1] = result.y; sb[2] = result.z;
+                    } else {
+                        store_pixel(out, prm.out_format, pix, result);
                     }
-                    sample++;
-                    if (sample < prm.spp) state = ST_NEW_SAMPLE;
-                    else {
-                        size_t o = ((size_t)lrow * (size_t)prm.width + (size_t)px) * 3;
-                        if (prm.out_format == 0) { float *f = (float *)out; f[o] = (float)c.x; f[o + 1] = (float)c.y; f[o + 2] = (float)c.z; }
-                        else if (prm.out_format == 1) { double *f = (double *)out; f[o] = c.x; f[o + 1] = c.y; f[o + 2] = c.z; }
-                        else {
-                            // toIntC (src/Image.hs:54-55): truncate (255 * min c 1), saturated to int16
-                            short *q = (short *)out;
-                            double v0 = 255 * hs_min(c.x, 1), v1 = 255 * hs_min(c.y, 1), v2 = 255 * hs_min(c.z, 1);
-                            q[o] = (short)(v0 < -32768.0 ? -32768 : (int)v0);
-                            q[o + 1] = (short)(v1 < -32768.0 ? -32768 : (int)v1);
-                            q[o + 2] = (short)(v2 < -32768.0 ? -32768 : (int)v2);
-                        }
-                        if (COUNT) cnt.c[CNT_PIXELS]++;
-                        state = ST_DONE;
-                    }
+                    if (COUNT) cnt.c[CNT_PIXELS]++;
+                    state = ST_DONE;
                     step = A_NONE;
                 } else {
                     int lv = fsp - 1;
@@ -870,10 +882,19 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         asm volatile("" ::: "memory");
     }
 
+#ifdef RAYHS_PROFILE_TIME
+    cnt.c[8] = __builtin_amdgcn_s_memrealtime() - rt0_;  // 100 MHz ticks over the wave's life
+    if (lane == 0 && counters != nullptr) {  // earliest start / latest end over all waves (slots 4, 5 are unused by the profile build)
+        atomicMax(&counters[4], ~rt0_);
+        atomicMax(&counters[5], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
+    cnt.c[9] = __builtin_amdgcn_s_memtime() - mt0_;      // shader-clock ticks over the wave's life
+#endif
     if ((COUNT || kProfileTime) && counters != nullptr) {
         for (int i = 0; i < 16; i++) {
             unsigned long long v = cnt.c[i];
-            if (kProfileTime && i >= 10 && lane != 0) v = 0;  // per-wave times: lane 0 only
+            if (kProfileTime && (i == 4 || i == 5)) continue;
+            if (kProfileTime && i >= 6 && lane != 0) v = 0;  // per-wave values: lane 0 only
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
             if (lane == 0 && v) atomicAdd(&counters[i], v);
         }
@@ -890,9 +911,20 @@ using namespace rayhs;
 #define RAYHS_DEFINE_KERNEL(NAME, EXH, COUNT, STACKT, WPE)                                                        \
     extern "C" __global__ void __launch_bounds__(TRACE_BLOCK, WPE)                                                \
     RAYHS_CAT(NAME, RAYHS_KERNEL_SUFFIX)(DScene sc, DCamera cam, DParams prm, void *out,                          \
-                                         unsigned long long *counters, unsigned int *ticket, double *frames) {    \
+                                         unsigned long long *counters, unsigned long long *ticket, double *frames) {\
         trace_body<EXH, COUNT, STACKT>(sc, cam, prm, out, counters, ticket, frames);                              \
     }
+
+// average (src/RayHs.hs:169-171): foldl (+) black over the samples in order, then mul (1 / n)
+extern "C" __global__ void __launch_bounds__(256)
+RAYHS_CAT(rayhs_resolve, RAYHS_KERNEL_SUFFIX)(const double *sbuf, void *out, int n_pixels, int spp, int out_format) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pixels) return;
+    const double *s = sbuf + (size_t)i * (size_t)spp * 3;
+    V3 sum = mk(0, 0, 0);
+    for (int k = 0; k < spp; k++) sum = add(sum, mk(s[3 * k], s[3 * k + 1], s[3 * k + 2]));
+    store_pixel(out, out_format, (size_t)i, scl(1.0 / (double)spp, sum));
+}
 
 RAYHS_DEFINE_KERNEL(rayhs_trace, false, false, unsigned short, RAYHS_WAVES_PER_EU)       // < 65536 BVH nodes
 RAYHS_DEFINE_KERNEL(rayhs_trace_wide, false, false, unsigned int, RAYHS_WAVES_PER_EU)   // any scene
@@ -915,9 +947,13 @@ static const void *RAYHS_CAT(kernel_ptr, RAYHS_KERNEL_SUFFIX)(int variant) {
 }
 hipError_t RAYHS_CAT(launch_trace, RAYHS_KERNEL_SUFFIX)(int variant, int grid, size_t lds_bytes, hipStream_t stream,
                                                         const DScene &sc, const DCamera &cam, const DParams &prm, void *out,
-                                                        unsigned long long *counters, unsigned int *ticket, double *frames) {
+                                                        unsigned long long *counters, unsigned long long *ticket, double *frames) {
     void *args[] = {(void *)&sc, (void *)&cam, (void *)&prm, (void *)&out, (void *)&counters, (void *)&ticket, (void *)&frames};
     return hipLaunchKernel(RAYHS_CAT(kernel_ptr, RAYHS_KERNEL_SUFFIX)(variant), dim3((unsigned)grid), dim3(TRACE_BLOCK), args, lds_bytes, stream);
+}
+hipError_t RAYHS_CAT(launch_resolve, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format) {
+    hipLaunchKernelGGL(RAYHS_CAT(rayhs_resolve, RAYHS_KERNEL_SUFFIX), dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream, sbuf, out, n_pixels, spp, out_format);
+    return hipGetLastError();
 }
 int RAYHS_CAT(occupancy_trace, RAYHS_KERNEL_SUFFIX)(int variant, size_t lds_bytes) {
     int n = 0;
