@@ -129,11 +129,9 @@ def main():
     stream = torch.cuda.current_stream()
 
     def step(ev=None):
-        if ev:
-            ev[0].record(stream)
-        r.ray_trace_device(g.local.data_ptr(), stream.cuda_stream, flags=flags, **kw)
-        if ev:
-            ev[1].record(stream)
+        # the library records the two HIP events on the stream right around the trace kernel itself
+        r.ray_trace_device(g.local.data_ptr(), stream.cuda_stream, flags=flags,
+                           events=(ev[0].cuda_event, ev[1].cuda_event) if ev else None, **kw)
         return g.gather()
 
     def sync_all():
@@ -159,6 +157,9 @@ def main():
     for _ in range(args.warmup):
         step()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in events:  # torch creates the underlying hipEvent lazily, on first record
+        a.record(stream)
+        b.record(stream)
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):

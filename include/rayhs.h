@@ -187,6 +187,13 @@ int rayhs_render_device(const rayhs_scene *scene, const rayhs_camera *camera,
                         const rayhs_render_params *params, void *d_out, void *hip_stream,
                         uint64_t *d_counters);
 
+/* Same as rayhs_render_device, and records two caller-owned HIP events (hipEvent_t, may be NULL) on the
+ * stream immediately before and after the TRACE kernel alone (not the ticket reset, not the resolve
+ * pass), so that a caller can time exactly the kernel a profiler reports. */
+int rayhs_render_device_events(const rayhs_scene *scene, const rayhs_camera *camera,
+                               const rayhs_render_params *params, void *d_out, void *hip_stream,
+                               uint64_t *d_counters, void *ev_before_trace, void *ev_after_trace);
+
 /* ---- host preparation (C++ restatement of the reference's L3/L4 host code;
  * the Haskell host would do this itself and call rayhs_scene_create) -------- */
 

@@ -122,11 +122,17 @@ class Rendering:
         L.check(L.load().rayhs_render(self._h, C.byref(self.desc.camera), C.byref(p), out.ctypes.data, C.byref(st)))
         return out, st.as_dict()
 
-    def ray_trace_device(self, d_out_ptr, stream_ptr=0, d_counters_ptr=0, **kw):
-        """Enqueue the trace into a caller-owned device buffer (no sync, no copy)."""
+    def ray_trace_device(self, d_out_ptr, stream_ptr=0, d_counters_ptr=0, events=None, **kw):
+        """Enqueue the trace into a caller-owned device buffer (no sync, no copy).  `events` = (before, after)
+        hipEvent_t handles recorded around the trace kernel alone."""
         p = self.params(**kw)
-        L.check(L.load().rayhs_render_device(self._h, C.byref(self.desc.camera), C.byref(p), C.c_void_p(d_out_ptr),
-                                             C.c_void_p(stream_ptr), C.c_void_p(d_counters_ptr)))
+        if events is None:
+            L.check(L.load().rayhs_render_device(self._h, C.byref(self.desc.camera), C.byref(p), C.c_void_p(d_out_ptr),
+                                                 C.c_void_p(stream_ptr), C.c_void_p(d_counters_ptr)))
+        else:
+            L.check(L.load().rayhs_render_device_events(self._h, C.byref(self.desc.camera), C.byref(p), C.c_void_p(d_out_ptr),
+                                                        C.c_void_p(stream_ptr), C.c_void_p(d_counters_ptr),
+                                                        C.c_void_p(events[0]), C.c_void_p(events[1])))
         return p
 
     def close(self):

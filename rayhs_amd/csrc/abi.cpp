@@ -494,18 +494,23 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
     hipError_t e = exact ? launch_trace_exact(variant, grid, lds, st, s->d, dc, dp, d_out, (unsigned long long *)d_counters, ticket, s->frames)
                          : launch_trace_fast(variant, grid, lds, st, s->d, dc, dp, d_out, (unsigned long long *)d_counters, ticket, s->frames);
     if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "trace kernel launch failed: %s", hipGetErrorString(e));
+    if (e1) HIP_TRY(hipEventRecord(e1, st));
     if (dp.spp > 1) {
         e = exact ? launch_resolve_exact(st, s->sbuf, d_out, dp.n_rows * dp.width, dp.spp, dp.out_format)
                   : launch_resolve_fast(st, s->sbuf, d_out, dp.n_rows * dp.width, dp.spp, dp.out_format);
         if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "resolve kernel launch failed: %s", hipGetErrorString(e));
     }
-    if (e1) HIP_TRY(hipEventRecord(e1, st));
     return RAYHS_OK;
 }
 
 extern "C" int rayhs_render_device(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_render_params *p, void *d_out,
                                    void *hip_stream, uint64_t *d_counters) {
     return launch(s, cam, p, d_out, (hipStream_t)hip_stream, d_counters, nullptr, nullptr);
+}
+
+extern "C" int rayhs_render_device_events(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_render_params *p, void *d_out,
+                                          void *hip_stream, uint64_t *d_counters, void *ev_before_trace, void *ev_after_trace) {
+    return launch(s, cam, p, d_out, (hipStream_t)hip_stream, d_counters, (hipEvent_t)ev_before_trace, (hipEvent_t)ev_after_trace);
 }
 
 extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_render_params *p, void *out_host, rayhs_stats *stats) {
@@ -542,7 +547,7 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
                 stats->nodes_tested = c[CNT_NODES]; stats->tris_tested = c[CNT_TRIS]; stats->prims_tested = c[CNT_PRIMS];
                 stats->shaded_hits = c[CNT_SHADED]; stats->pixels = c[CNT_PIXELS] / (unsigned long long)std::max(p->spp, 1);  // the kernel counts samples
                 if (std::getenv("RAYHS_DEBUG_COUNTERS"))  // development: raw loop counters of a -DRAYHS_PROFILE_LOOPS build
-                    std::fprintf(stderr, "rayhs span_ticks %llu counters[6..15]: %llu %llu | %llu %llu | %llu %llu %llu %llu %llu %llu  kernel_ms %.3f\n", c[5] - ~c[4], c[6], c[7], c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], (double)ms);
+                    std::fprintf(stderr, "rayhs adv[0..3] %llu %llu %llu %llu span_ticks %llu counters[6..15]: %llu %llu | %llu %llu | %llu %llu %llu %llu %llu %llu  kernel_ms %.3f\n", c[0], c[1], c[2], c[3], c[5] - ~c[4], c[6], c[7], c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], (double)ms);
             }
         }
     } while (0);

@@ -129,6 +129,11 @@ enum { CNT_PRIMARY = 0, CNT_REFLECT, CNT_REFRACT, CNT_REFRACT_EXIT, CNT_SHADOW, 
 static constexpr int TRACE_BLOCK = 256;     // threads per workgroup (4 waves)
 static constexpr int FRAME_SLOTS = 14;      // doubles per continuation frame
 static constexpr int LANE_SLOTS = 6;        // per-lane doubles kept in the global workspace besides frames (view dir, light term)
-static constexpr int CTX_SLOTS = 12;        // per-lane doubles parked in LDS across a shadow / exit query (p, n, cd, A)
+#ifndef RAYHS_CTX_SLOTS
+#define RAYHS_CTX_SLOTS 12
+#endif
+// per-lane doubles parked in LDS across a shadow / exit query: p, n, cd, A; with 18 also the light term
+// and the view direction (otherwise those two go through the global workspace)
+static constexpr int CTX_SLOTS = RAYHS_CTX_SLOTS;
 
 }  // namespace rayhs

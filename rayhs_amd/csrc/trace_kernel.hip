@@ -567,9 +567,15 @@ DEV V3 ws_load3(const double *ws, int stride, int slot) { return mk(ws_load(ws, 
 DEV int fslot(int level, int s) { return LANE_SLOTS + level * FRAME_SLOTS + s; }
 
 // ---- LDS context slots (12 doubles per lane) ----
-enum : int { CX_P = 0, CX_N = 3, CX_CD = 6, CX_A = 9 };
+enum : int { CX_P = 0, CX_N = 3, CX_CD = 6, CX_A = 9, CX_TERM = 12, CX_V = 15 };
+constexpr bool kWideCtx = CTX_SLOTS >= 18;
 DEV void cx_store3(lds_dptr cx, int slot, V3 v) { cx[slot * TRACE_BLOCK] = v.x; cx[(slot + 1) * TRACE_BLOCK] = v.y; cx[(slot + 2) * TRACE_BLOCK] = v.z; }
 DEV V3 cx_load3(lds_dptr cx, int slot) { return mk(cx[slot * TRACE_BLOCK], cx[(slot + 1) * TRACE_BLOCK], cx[(slot + 2) * TRACE_BLOCK]); }
+
+#define PARK_V(v) do { if (kWideCtx) cx_store3(cx, CX_V, v); else ws_store3(ws, stride, LS_V, v); } while (0)
+#define LOAD_V() (kWideCtx ? cx_load3(cx, CX_V) : ws_load3(ws, stride, LS_V))
+#define PARK_TERM(v) do { if (kWideCtx) cx_store3(cx, CX_TERM, v); else ws_store3(ws, stride, LS_TERM, v); } while (0)
+#define LOAD_TERM() (kWideCtx ? cx_load3(cx, CX_TERM) : ws_load3(ws, stride, LS_TERM))
 
 template <bool EXH, bool COUNT, typename StackT>
 static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DParams &prm, void *out,
@@ -657,6 +663,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         // ---- advance: consume the last query's answer, run shading up to the next query.
         // Straight-line sections (hit / shadow / exit -> lights -> specular -> return -> next sample)
         // keep the live ranges short; everything declared in this block dies before the query below.
+        TIME_ADD(0);  // refill
         // Lanes whose ray is still in flight keep their state; the others consume their answer.
         const bool was_traversing = tr.traversing();
         if (!was_traversing) qkind = Q_NONE;
@@ -676,7 +683,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                     const auto &ob = as_const(sc.objects)[tr.bobj];
                     if (COUNT) cnt.c[CNT_SHADED]++;
                     c_obj = tr.bobj;
-                    ws_store3(ws, stride, LS_V, ray.d);
+                    PARK_V(ray.d);
                     c_p = add(ray.o, scl(tr.bt, ray.d));  // rayAt (src/Geometry.hs:27-29)
                     double hu = 0, hv = 0;
                     const int mat_kind = ob.mat_kind;
@@ -722,7 +729,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
             } else if (state == ST_SHADOW) {
                 // accumDiffuse fold step (src/RayHs.hs:90-96)
                 c_p = cx_load3(cx, CX_P); c_n = cx_load3(cx, CX_N); c_cd = cx_load3(cx, CX_CD);
-                c_A = add(cx_load3(cx, CX_A), occluded ? mk(0, 0, 0) : ws_load3(ws, stride, LS_TERM));
+                c_A = add(cx_load3(cx, CX_A), occluded ? mk(0, 0, 0) : LOAD_TERM());
                 c_li++;
                 step = A_LIGHT_NEXT;
             } else if (state == ST_EXIT) {
@@ -743,7 +750,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                     if (refract(c_cd, neg(outn), ob.ior, 1.0, outdir)) {
                         have = true;
                         // suspend this irradiance call: radiance child first, specular child later
-                        V3 c_v = ws_load3(ws, stride, LS_V);
+                        V3 c_v = LOAD_V();
                         V3 rf = reflect(c_v, c_n);
                         ws_store(ws, stride, fslot(fsp, FS_KIND), (double)FR_TRANS_WAIT_RADIANCE);
                         ws_store(ws, stride, fslot(fsp, FS_DEPTH), (double)depth);
@@ -762,6 +769,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                 if (!have) { spec_with_A = false; step = A_SPEC; }
             }
 
+            TIME_ADD(1);  // hit / shadow / exit sections
             if (step == A_LIGHT_NEXT) {
                 if (c_li < sc.n_lights) {
                     // lightAt (src/Light.hs:12-17) + diffuse (src/Material.hs:31-33)
@@ -778,7 +786,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                         q_point = true; q_dist = d;
                     }
                     // the light's diffuse term, added after the shadow query if unoccluded
-                    ws_store3(ws, stride, LS_TERM, scl(hs_max(dot(ld, c_n), 0) * kPiInv, mulv(c_cd, lc)));
+                    PARK_TERM(scl(hs_max(dot(ld, c_n), 0) * kPiInv, mulv(c_cd, lc)));
                     ray.o = add(c_p, scl(kEps, ld)); ray.d = ld;  // rayEps p ld
                     if (q_point) { V3 dd = sub(ray.o, ld3(L.v)); q_d2 = dot(dd, dd); }  // sqrDist origin p (src/RayHs.hs:87)
                     if (COUNT) cnt.c[CNT_SHADOW]++;
@@ -794,10 +802,11 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                 cx_store3(cx, CX_P, c_p); cx_store3(cx, CX_N, c_n); cx_store3(cx, CX_CD, c_cd);
             }
 
+            TIME_ADD(2);  // light section
             if (step == A_SPEC) {
                 // fresnel * specular (src/RayHs.hs:99-104,119,124,132)
                 const auto &ob = as_const(sc.objects)[c_obj];
-                V3 c_v = ws_load3(ws, stride, LS_V);
+                V3 c_v = LOAD_V();
                 double F = fresnel(ob.fr, dot(c_n, neg(c_v)));
                 if (depth < prm.max_depth) {
                     V3 rf = reflect(c_v, c_n);
@@ -818,6 +827,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                 }
             }
 
+            TIME_ADD(3);  // specular section
             // hand `result` to the suspended callers until one needs another ray, or the sample is done
             while (step == A_RETURN) {
                 if (fsp == 0) {
@@ -896,7 +906,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         for (int i = 0; i < 16; i++) {
             unsigned long long v = cnt.c[i];
             if (kProfileTime && (i == 4 || i == 5)) continue;
-            if (kProfileTime && i >= 6 && lane != 0) v = 0;  // per-wave values: lane 0 only
+            if (kProfileTime && (i >= 6 || i < 4) && lane != 0) v = 0;  // per-wave values: lane 0 only
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
             if (lane == 0 && v) atomicAdd(&counters[i], v);
         }

@@ -77,6 +77,8 @@ SYMBOLS = [
     ("rayhs_render_rows", C.c_int, [C.POINTER(RenderParams)]),
     ("rayhs_render", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),
     ("rayhs_render_device", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("rayhs_render_device_events", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
     ("rayhs_render_desc_load", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     ("rayhs_render_desc_parse", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     ("rayhs_render_desc_free", None, [C.c_void_p]),
