@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--workload", default="dragon", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--fma", action="store_true", help="use the fused-multiply-add kernels (not bit-exact with the reference)")
+    ap.add_argument("--verify", action="store_true",
+                    help="rank 0 also renders the whole frame by itself and checks that the gathered frame is identical")
     args = ap.parse_args()
 
     import torch
@@ -113,26 +115,46 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if L.load().rayhs_device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; the trace path has no CPU fallback")
+    # Test hooks (tests/test_gpu_parity.py): rehearse the N > 1 path on a one-GPU box -- every rank on
+    # device 0, gloo instead of RCCL.  Never set by the driver.
+    if os.environ.get("RAYHS_BENCH_ONE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("RAYHS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     scene, spp, desc = WORKLOADS[args.workload]
     rd = RenderDesc(scene)
     r = Rendering(rd, device=local_rank)
     w, h = r.width, r.height
-    g = tiles.FrameGather(rank, world, h, w, STRIPE_ROWS, dev, torch.float32)
+    # two frame slots: the gather of frame i (RCCL, its own stream) overlaps the trace of frame i + 1
+    slots = [tiles.FrameGather(rank, world, h, w, STRIPE_ROWS, dev, torch.float32) for _ in range(2)]
+    g = slots[0]
     flags = L.FLAG_FMA if args.fma else 0
     kw = dict(spp=spp, seed=24, stripe_rows=STRIPE_ROWS, stripe_rank=rank, stripe_count=world, out_format=L.OUT_F32)
     stream = torch.cuda.current_stream()
 
-    def step(ev=None):
+    pending = []
+
+    def step(i, ev=None):
+        cur = slots[i % 2]
         # the library records the two HIP events on the stream right around the trace kernel itself
-        r.ray_trace_device(g.local.data_ptr(), stream.cuda_stream, flags=flags,
+        r.ray_trace_device(cur.local.data_ptr(), stream.cuda_stream, flags=flags,
                            events=(ev[0].cuda_event, ev[1].cuda_event) if ev else None, **kw)
-        return g.gather()
+        cur.gather_start()
+        if pending:
+            pending.pop().gather_finish()  # frame i - 1: its transfer ran beside this frame's trace
+        pending.append(cur)
+
+    def drain():
+        while pending:
+            pending.pop().gather_finish()
 
     def sync_all():
         torch.cuda.synchronize()
@@ -154,8 +176,9 @@ def main():
     tot = dict(zip(names, total[:10].tolist()))
     rays_frame = sum(v for k, v in tot.items() if k.startswith("rays_"))
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    drain()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b in events:  # torch creates the underlying hipEvent lazily, on first record
         a.record(stream)
@@ -163,7 +186,8 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(events[i])
+        step(i, events[i])
+    drain()  # every frame is gathered and assembled inside the timed region
     sync_all()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -173,8 +197,16 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
 
     if rank == 0:
-        frame = g.frame
+        frame = slots[(args.steps - 1) % 2].frame
         assert torch.isfinite(frame).all() and frame.shape == (h, w, 3)
+        verified = None
+        if args.verify:
+            whole = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
+            r.ray_trace_device(whole.data_ptr(), stream.cuda_stream, flags=flags, spp=spp, seed=24, out_format=L.OUT_F32)
+            torch.cuda.synchronize()
+            verified = bool(torch.equal(whole, frame))
+            if not verified:
+                raise SystemExit("bench.py --verify: the gathered frame differs from the single-rank render")
         alg = algorithmic_bytes(mine)
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -186,7 +218,7 @@ def main():
                        "sharding": f"{STRIPE_ROWS}-row stripes interleaved over {world} rank(s), one gather to rank 0",
                        "kernels": "fma" if args.fma else "exact (-ffp-contract=off, bit-identical to the CPU oracle)"},
             "mpixels_per_s": w * h * args.steps / dt / 1e6,
-            "rays_per_frame": rays_frame, "kernel_ms_rank0": kernel_ms,
+            "rays_per_frame": rays_frame, "kernel_ms_rank0": kernel_ms, "verified_against_single_rank": verified,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(args.workload) if world == 1 else None,
                          "algorithmic_bytes_per_launch": alg,

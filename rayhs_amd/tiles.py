@@ -62,10 +62,23 @@ class FrameGather:
 
     def gather(self):
         """Returns the assembled frame on rank 0 (None elsewhere)."""
+        self.gather_start()
+        return self.gather_finish()
+
+    def gather_start(self):
+        """Enqueue the collective without blocking the calling stream; pair with gather_finish().
+        Between the two the caller may enqueue work that does not touch `local` (e.g. render the next
+        frame into another FrameGather), which then overlaps with the transfer."""
+        self._work = None
+        if self.world > 1:
+            self._work = dist.gather(self.local, self.parts if self.rank == 0 else None, dst=0, async_op=True)
+
+    def gather_finish(self):
         if self.world == 1:
             self.frame.copy_(self.local[: self.height])
             return self.frame
-        dist.gather(self.local, self.parts if self.rank == 0 else None, dst=0)
+        self._work.wait()  # makes the current stream wait for the collective; does not block the host
+        self._work = None
         if self.rank != 0:
             return None
         flat = self.stacked.view(self.world * self.pad_rows, self.width, self.channels)

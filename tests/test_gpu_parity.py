@@ -13,6 +13,7 @@ import ctypes as C
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -264,3 +265,23 @@ def test_headline_scene_band_against_oracle():
     want, _ = oracle_image(scene, spp=16, row0=600, row1=602)
     assert np.array_equal(part, want)
     r.close()
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    # the N > 1 path of bench.py (stripes, gather, assembly, counter reduction) with two ranks sharing
+    # the one GPU of this box over gloo; the driver runs the real thing over RCCL on 8 GPUs
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RAYHS_BENCH_ONE_DEVICE="1", RAYHS_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "dragon_low", "--cpu-seconds", "0", "--verify"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["verified_against_single_rank"] is True
+    assert out["metric"] == "Mrays/s" and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["rays_per_frame"] > 1920 * 1080 * 4
