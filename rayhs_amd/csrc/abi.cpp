@@ -483,7 +483,7 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
     int rc = prepare_launch(s, cam, p, dc, dp, variant, exact, grid, lds);
     if (rc) return rc;
     if (!d_out) return set_error(RAYHS_ERR_INVALID, "d_out is NULL");
-    if (variant != 0 && !d_counters) return set_error(RAYHS_ERR_INVALID, "RAYHS_FLAG_COUNT needs d_counters");
+    if ((variant == 1 || variant == 2) && !d_counters) return set_error(RAYHS_ERR_INVALID, "RAYHS_FLAG_COUNT needs d_counters");
     if (dp.n_tiles == 0) return RAYHS_OK;
     HIP_TRY(hipSetDevice(s->device));
     if ((rc = ensure_workspace(s, dp))) return rc;

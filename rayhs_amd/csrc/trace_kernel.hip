@@ -501,6 +501,12 @@ struct Tracer {
             // memory round trip per visit) and both child boxes are always tested.
             while (t_cur != FNODE_NONE && t_pa == FNODE_NONE) {
                 LOOP_TICK(10);
+#ifdef RAYHS_PROFILE_LOOPS
+                if (COUNT) {  // coherence probe: how many active lanes sit on the same node as the first active lane
+                    const int leader = __builtin_amdgcn_readfirstlane(t_cur);
+                    if (t_cur == leader) cnt.c[14]++;
+                }
+#endif
                 const FNode nd = sc.fnodes[t_cur];
                 float tn0, tn1;
                 const bool h0 = qbox(nd.lo0, nd.hi0, t_ax, t_ay, t_az, t_bx, t_by, t_bz, limf, tn0) & (nd.c0 != FNODE_NONE);
@@ -614,6 +620,8 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     const unsigned long long total_items = (unsigned long long)prm.n_tiles * 64ull * (unsigned long long)prm.spp;
     unsigned long long pool_next = 0, pool_end = 0;
     bool exhausted = false;
+    unsigned long long ticket_ahead = 0;  // lane 0: ticket requested ahead of need
+    if (lane == 0) ticket_ahead = atomicAdd(ticket, (unsigned long long)kChunk);
 
     TIME_DECL;
 #ifdef RAYHS_PROFILE_TIME
@@ -624,8 +632,10 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         if (__popcll(idle) < RAYHS_REFILL_MIN) idle = 0ull;
         while (idle != 0ull && !exhausted) {  // wave-uniform
             if (pool_next == pool_end) {
-                unsigned long long c = 0;
-                if (lane == 0) c = atomicAdd(ticket, (unsigned long long)kChunk);
+                // the ticket for this chunk was requested one refill ago; request the next one now, so that the
+                // atomic's round trip (microseconds) runs beside the chunk's work instead of in front of it
+                unsigned long long c = ticket_ahead;
+                if (lane == 0) ticket_ahead = atomicAdd(ticket, (unsigned long long)kChunk);
                 c = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(c >> 32)) << 32) |
                     (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)c);
                 pool_next = c;
@@ -669,7 +679,6 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         if (!was_traversing) qkind = Q_NONE;
         occluded = tr.occ;
         if (state != ST_DONE && !was_traversing) {
-            LOOP_TICK(14);
             V3 result = mk(0, 0, 0);
             V3 c_p = mk(0, 0, 0), c_n = mk(0, 0, 0), c_cd = mk(0, 0, 0), c_A = mk(0, 0, 0);
             enum : int { A_NONE, A_LIGHT_NEXT, A_SPEC, A_RETURN, A_QUERY_READY };

@@ -285,3 +285,45 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert out["n_gpus"] == 2 and out["verified_against_single_rank"] is True
     assert out["metric"] == "Mrays/s" and out["value"] > 0 and out["scaling"] == "strong"
     assert out["rays_per_frame"] > 1920 * 1080 * 4
+
+
+def test_timed_entry_point_records_events_around_the_trace_kernel():
+    import torch
+    r = build_rendering("scenes/dragon_superlow_96.json")
+    want, _ = r.ray_trace(spp=4, out_format=L.OUT_F32)
+    out = torch.zeros((96, 96, 3), dtype=torch.float32, device="cuda:0")
+    s = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    e1.record(s)   # torch creates the hipEvent on first record
+    r.ray_trace_device(out.data_ptr(), s.cuda_stream, events=(e0.cuda_event, e1.cuda_event), spp=4, out_format=L.OUT_F32)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert 0.0 < e0.elapsed_time(e1) < 1000.0
+    r.close()
+
+
+def test_large_mesh_uses_the_wide_stack_kernel(tmp_path):
+    # > 65535 BVH nodes: 16-bit stack entries no longer fit, the 32-bit-stack kernel is selected
+    n = 280                                        # 2 * 279^2 = 155,682 triangles
+    xs = np.linspace(-1.0, 1.0, n)
+    zz = 0.15 * np.sin(3.1 * xs)[:, None] * np.cos(2.3 * xs)[None, :]
+    lines = []
+    for j in range(n):
+        for i in range(n):
+            lines.append(f"v {xs[i]:.6f} {xs[j]:.6f} {zz[j, i] + 1.5:.6f}")
+    lines.append("vn 0 0 -1")
+    for j in range(n - 1):
+        for i in range(n - 1):
+            a, b, c, d = j * n + i + 1, j * n + i + 2, (j + 1) * n + i + 1, (j + 1) * n + i + 2
+            lines.append(f"f {a}//1 {b}//1 {d}//1")
+            lines.append(f"f {a}//1 {d}//1 {c}//1")
+    obj = tmp_path / "sheet.obj"
+    obj.write_text("\n".join(lines) + "\n")
+    mesh = {"geometry": {"type": "mesh", "fileName": str(obj), "transform": {"type": "rotateY", "angle": 0.3}},
+            "material": {"type": "plastic", "ior": 1.6, "cd": {"type": "flat", "color": {"r": 1, "g": 0.7, "b": 0.4}}}}
+    got, want, st, ost = _both(_scene_json([mesh, GLASS], [PT, DIR], w=40, h=24, depth=2), tmp_path)
+    assert np.array_equal(got, want) and st["rays"] == ost["rays"]
+    p = tmp_path / "s.json"
+    fast, _ = rayhs_amd.ray_trace_file(str(p))       # non-counting run -> the wide kernel itself
+    assert np.array_equal(fast, want)
