@@ -533,26 +533,39 @@ int to_int_c(double c) {
     return (int)v;
 }
 
-// writePPM / formatPixelsPPM (src/Image.hs:60-75)
+// writePPM / formatPixelsPPM (src/Image.hs:60-75): "P3\nW H\n255\n", rows joined by '\n', every pixel
+// "r g b" followed by two spaces, no trailing newline.  A 1080p frame is ~20 MB of ASCII (4K: ~80 MB), so
+// the digits are emitted by hand into one buffer (no printf per pixel) and written with a single fwrite.
+static inline char *put_int(char *p, int v) {
+    unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    if (v < 0) *p++ = '-';
+    char tmp[12];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
 template <class Get>
 static void write_ppm_impl(const std::string &path, int w, int h, Get get) {
     FILE *f = std::fopen(path.c_str(), "wb");
     if (!f) throw SceneError(RAYHS_ERR_IO, path + ": openFile: permission denied or missing directory");
-    std::string buf;
-    buf.reserve(1 << 22);
-    buf += "P3\n" + std::to_string(w) + " " + std::to_string(h) + "\n255\n";
-    char tmp[64];
+    const std::string head = "P3\n" + std::to_string(w) + " " + std::to_string(h) + "\n255\n";
+    std::vector<char> buf(head.size() + (size_t)w * (size_t)h * 23 + (size_t)h + 16);  // <= 3 x "-32768" + separators per pixel
+    char *p = buf.data();
+    std::memcpy(p, head.data(), head.size());
+    p += head.size();
     for (int y = 0; y < h; y++) {
-        if (y) buf += '\n';
+        if (y) *p++ = '\n';
         for (int x = 0; x < w; x++) {
             size_t i = ((size_t)y * (size_t)w + (size_t)x) * 3;
-            int n = std::snprintf(tmp, sizeof tmp, "%d %d %d  ", get(i), get(i + 1), get(i + 2));
-            buf.append(tmp, (size_t)n);
+            p = put_int(p, get(i)); *p++ = ' ';
+            p = put_int(p, get(i + 1)); *p++ = ' ';
+            p = put_int(p, get(i + 2)); *p++ = ' '; *p++ = ' ';
         }
-        if (buf.size() > (1u << 22) - 65536) { std::fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
     }
-    std::fwrite(buf.data(), 1, buf.size(), f);
-    if (std::fclose(f) != 0) throw SceneError(RAYHS_ERR_IO, path + ": write failed");
+    size_t n = (size_t)(p - buf.data());
+    bool ok = std::fwrite(buf.data(), 1, n, f) == n;
+    if (std::fclose(f) != 0 || !ok) throw SceneError(RAYHS_ERR_IO, path + ": write failed");
 }
 void write_ppm_i16(const std::string &path, int w, int h, const int16_t *q) {
     write_ppm_impl(path, w, h, [q](size_t i) { return (int)q[i]; });
