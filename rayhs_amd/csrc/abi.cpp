@@ -449,6 +449,9 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
         if (per_cu <= 0) return set_error(RAYHS_ERR_HIP, "trace kernel cannot be resident (occupancy query returned %d)", per_cu);
         if (const char *e = std::getenv("RAYHS_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // development knob
         cache[0] = (int)lds; cache[1] = per_cu;
+        if (std::getenv("RAYHS_DEBUG_COUNTERS"))
+            std::fprintf(stderr, "rayhs launch: variant %d, lds %zu B, %d blocks/CU, stack cap %d (ref depth %d, bvh depth %d)\n", variant, lds, per_cu,
+                         dp.stack_cap, s->tree_depth, s->fast_depth);
     }
     int wanted = (dp.n_tiles + 3) / 4;  // 4 waves per workgroup, one tile per wave at a time
     grid = std::max(1, std::min(wanted, s->cu_count * cache[1]));

@@ -266,6 +266,8 @@ struct Tracer {
         return t_cur != FNODE_NONE || t_pa != FNODE_NONE || t_sp > 0 || t_m < sc.n_meshes;
     }
     __device__ __forceinline__ void stop_traversal() { t_cur = FNODE_NONE; t_pa = FNODE_NONE; t_pb = FNODE_NONE; t_sp = 0; t_m = sc.n_meshes; }
+    // without time slicing a query always ends inside slice(): say so to the register allocator
+    __device__ __forceinline__ void forget_traversal() { stop_traversal(); t_obj = 0; t_ax = t_ay = t_az = t_bx = t_by = t_bz = t_enter = 0; }
 
     __device__ Tracer(const DScene &s, stack_ptr st, Counters &c) : sc(s), stack(st), cnt(c) {
         bt = 0; bu = 0; bv = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; occ = false;
@@ -675,7 +677,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         // keep the live ranges short; everything declared in this block dies before the query below.
         TIME_ADD(0);  // refill
         // Lanes whose ray is still in flight keep their state; the others consume their answer.
-        const bool was_traversing = tr.traversing();
+        const bool was_traversing = RAYHS_SLICE_MIN > 0 && tr.traversing();
         if (!was_traversing) qkind = Q_NONE;
         occluded = tr.occ;
         if (state != ST_DONE && !was_traversing) {
@@ -899,6 +901,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         tr.begin(was_traversing ? Q_NONE : qkind, ray, q_point, q_d2);
         TIME_ADD(11);
         tr.slice(qkind == Q_SHADOW, ray, q_point, q_d2, q_dist, state != ST_DONE || !exhausted);
+        if (RAYHS_SLICE_MIN == 0) tr.forget_traversal();
         TIME_ADD(15);
         asm volatile("" ::: "memory");
     }
