@@ -613,7 +613,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     bool occluded = false;
 
     // Work items are (pixel, sample) pairs: item / spp is a pixel slot in 8x8-tile order (slot >> 6 = tile,
-    // slot & 63 = position in the tile), item % spp the sample.  A wave draws chunks of kChunk items from
+    // slot & 63 = Morton position in the tile), item % spp the sample.  A wave draws chunks of kChunk items from
     // the global ticket into a wave-local pool and hands them to its idle lanes, so a lane that finishes a
     // sample gets the next one at once.  (Per-pixel items left the frame waiting on single lanes that
     // held an expensive pixel: 16 samples in sequence.)  With spp > 1 every sample's radiance goes to a
@@ -657,8 +657,10 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                 sample = (int)(item - (unsigned long long)slot * (unsigned)prm.spp);
                 const int tile = (int)(slot >> 6), within = (int)(slot & 63u);
                 const int ty = tile / prm.tiles_x, tx = tile - ty * prm.tiles_x;
-                px = tx * 8 + (within & 7);
-                lrow = ty * 8 + (within >> 3);
+                // Morton order inside the tile: consecutive slots form 2x2, 4x4, ... blocks, so the few pixels a
+                // wave holds at once are neighbours in both directions
+                px = tx * 8 + ((within & 1) | ((within >> 1) & 2) | ((within >> 2) & 4));
+                lrow = ty * 8 + (((within >> 1) & 1) | ((within >> 2) & 2) | ((within >> 3) & 4));
                 if (px < prm.width && lrow < prm.n_rows) {
                     // local row -> image row (stripe interleave, include/rayhs.h)
                     int s_local = lrow / prm.stripe_rows, in_stripe = lrow - s_local * prm.stripe_rows;

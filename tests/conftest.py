@@ -16,3 +16,12 @@ def pytest_configure(config):
 def _repo_cwd(monkeypatch):
     # scene files name meshes relative to the working directory (src/Mesh.hs:218-221)
     monkeypatch.chdir(ROOT)
+
+
+def pytest_sessionstart(session):
+    # the C-ABI library and the oracle are build products (git-ignored); build them if this checkout has none
+    lib = os.path.join(ROOT, "rayhs_amd", "bin", "librayhs_hip.so")
+    orc = os.path.join(ROOT, "oracle", "librayhs_oracle.so")
+    if not (os.path.exists(lib) and os.path.exists(orc)):
+        import __graft_entry__
+        __graft_entry__.build()
