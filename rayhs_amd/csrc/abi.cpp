@@ -162,8 +162,12 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
         for (int c = 0; c < 3; c++) { n.lo[c] = d.node_lo[3 * k + c]; n.hi[c] = d.node_hi[3 * k + c]; }
         if (d.node_tri_count[k] >= 0) { n.a = d.node_first_tri[k]; n.b = d.node_tri_count[k]; n.flags = DNODE_LEAF; }
         else { n.a = d.node_left[k]; n.b = d.node_right[k]; n.flags = d.node_axis[k] & 3; }
-        n.pad = 0;
+        n.parent = -1;
     }
+    for (int k = 0; k < d.n_nodes; k++)
+        if (d.node_tri_count[k] < 0)
+            for (int c : {d.node_left[k], d.node_right[k]})
+                if (c >= 0) nodes[(size_t)c].parent = k;
     auto pack_tri = [&](int k, DTri &t, DTriAttr &a) {
         const double *p = d.tri_pos + 9 * (size_t)k;
         for (int c = 0; c < 3; c++) {
@@ -174,7 +178,7 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
         const double *n = d.tri_nrm + 9 * (size_t)k, *uv = d.tri_uv + 6 * (size_t)k;
         for (int c = 0; c < 3; c++) { a.n0[c] = n[c]; a.n1[c] = n[3 + c]; a.n2[c] = n[6 + c]; }
         for (int c = 0; c < 2; c++) { a.uv0[c] = uv[c]; a.uv1[c] = uv[2 + c]; a.uv2[c] = uv[4 + c]; }
-        a.pad = 0;
+        a.leaf_node = -1; a.pad = 0;
     };
     std::vector<DTri> tris((size_t)d.n_tris);
     std::vector<DTriAttr> attrs((size_t)d.n_tris);
@@ -204,6 +208,7 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
                     int t = d.node_first_tri[k] + i;
                     tris[(size_t)t].rank = (int)ids.size();
                     tris[(size_t)t].leaf_first = first_rank;
+                    attrs[(size_t)t].leaf_node = k;
                     ids.push_back(t);
                 }
             } else {

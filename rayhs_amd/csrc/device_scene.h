@@ -18,7 +18,7 @@ struct alignas(16) DNode {
     double lo[3], hi[3];  // Box (src/KDTree.hs:13-14)
     int32_t a, b;         // inner: left/right child (-1 = Empty); leaf: first triangle, count
     int32_t flags;        // bit 31 = leaf, bits 0..1 = split axis of an inner node
-    int32_t pad;
+    int32_t parent;       // parent node, -1 for a root
 };
 static constexpr int32_t DNODE_LEAF = (int32_t)0x80000000;
 
@@ -46,7 +46,8 @@ struct alignas(16) DTri {
 struct alignas(16) DTriAttr {
     double n0[3], n1[3], n2[3];
     double uv0[2], uv1[2], uv2[2];
-    double pad;
+    int32_t leaf_node;    // reference-tree leaf holding the triangle (BVH-ordered copy only)
+    int32_t pad;
 };
 
 struct DPlane {   // src/Geometry.hs:62, 70-79

@@ -194,6 +194,27 @@ static __device__ __attribute__((noinline)) V3 color_at_slow(cptr<DObject> objec
 
 struct Ray { V3 o, d; };
 
+// The reference reaches a triangle only through the fp64 slab tests of its leaf and of every ancestor
+// (src/KDTree.hs:39-56, 96-107).  Those tests are exact up to rounding, so a ray that hits the triangle's
+// interior passes them; a ray through an edge or a vertex -- which lie ON the box faces -- may fail one by
+// an ulp, and the reference then never sees the hit.  For such near-edge candidates of the fast BVH the
+// reference's own path is replayed.  Out of line: it runs for about one hit in a million.
+static __device__ __attribute__((noinline)) bool reference_path_admits(const DNode *nodes, int leaf_node, V3 o, V3 d) {
+    const V3 inv = mk(1 / d.x, 1 / d.y, 1 / d.z);
+    for (int n = leaf_node; n >= 0;) {
+        const DNode nd = nodes[n];
+        double t1 = inv.x * (nd.lo[0] - o.x), t2 = inv.x * (nd.hi[0] - o.x);
+        double t3 = inv.y * (nd.lo[1] - o.y), t4 = inv.y * (nd.hi[1] - o.y);
+        double t5 = inv.z * (nd.lo[2] - o.z), t6 = inv.z * (nd.hi[2] - o.z);
+        double tmin = hs_max(hs_max(hs_min(t1, t2), hs_min(t3, t4)), hs_min(t5, t6));
+        double tmax = hs_min(hs_min(hs_max(t1, t2), hs_max(t3, t4)), hs_max(t5, t6));
+        if (tmax < 0 || tmin > tmax) return false;
+        n = nd.parent;
+    }
+    return true;
+}
+constexpr double kEdgeBand = 1e-6;  // barycentric distance from an edge below which the path is replayed
+
 // rayFromPixel (src/Projection.hs:22-39); camera constants precomputed on the host
 DEV Ray ray_from_pixel(const DCamera &c, double px, double py) {
     double vx = c.apw * (px - c.half_w) / c.w;
@@ -544,8 +565,13 @@ struct Tracer {
                     if (COUNT) cnt.c[CNT_TRIS]++;
                     double t, u, v;
                     if (tri_test(tr, r, t, u, v)) {
-                        if (shadow) occ = occ || in_front(r, t, point_light, light_d2);
-                        else if (offer(t, u, v, t_obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - (double)t_enter); }
+                        bool admitted = true;
+                        if (u < kEdgeBand || v < kEdgeBand || (u + v) > 1 - kEdgeBand)
+                            admitted = reference_path_admits(sc.nodes, sc.fattrs[k].leaf_node, r.o, r.d);
+                        if (admitted) {
+                            if (shadow) occ = occ || in_front(r, t, point_light, light_d2);
+                            else if (offer(t, u, v, t_obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - (double)t_enter); }
+                        }
                     }
                 }
                 t_pa = t_pb;

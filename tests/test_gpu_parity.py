@@ -386,3 +386,44 @@ def test_random_scenes_bit_exact(tmp_path, seed):
     same = (got == want) | (np.isnan(got) & np.isnan(want))     # NaN colours are legal (e.g. 0/0 in a degenerate scene)
     assert same.all(), (seed, np.abs(np.nan_to_num(got) - np.nan_to_num(want)).max(), int((~same).any(axis=2).sum()))
     assert st["rays"] == ost["rays"], seed
+
+
+def test_rays_through_mesh_vertices_and_edges(tmp_path):
+    # Adversarial for the culling structure and the tie rule: an orthographic camera whose pixel rays pass
+    # through the vertices of a triangulated height field to within an ulp (vertices were placed ON the rays),
+    # so every primary ray hits up to six triangles at (almost) the same t, right on the faces of their leaf
+    # boxes.  The fast BVH, the reference tree and the oracle must still agree bit for bit.
+    n = 48
+    pos, target = (0.3, -0.2, -5.0), (1.7, 0.4, -3.0)
+    fwd = np.array(target) - np.array(pos)
+    fwd = fwd * (1 / np.sqrt(np.dot(fwd, fwd)))
+    lines = []
+    for j in range(n + 1):          # one vertex per pixel-corner ray of an (n x n) image, plus the last row/column
+        for i in range(n + 1):
+            o = np.array([float(i - n // 2) + pos[0], float(n // 2 - j) + pos[1], pos[2]])
+            s = 6.0 + 0.9 * np.sin(0.37 * i) + 0.7 * np.cos(0.23 * j) + 0.011 * ((i * 7 + j * 13) % 5)
+            v = o + s * fwd
+            lines.append("v %s %s %s" % tuple(repr(float(c)) for c in v))
+    lines.append("vn 0.1 0.2 -1")
+    for j in range(n):
+        for i in range(n):
+            a, b, c, d = j * (n + 1) + i + 1, j * (n + 1) + i + 2, (j + 1) * (n + 1) + i + 1, (j + 1) * (n + 1) + i + 2
+            lines.append(f"f {a}//1 {b}//1 {d}//1")
+            lines.append(f"f {a}//1 {d}//1 {c}//1")
+    obj = tmp_path / "field.obj"
+    obj.write_text("\n".join(lines) + "\n")
+    mesh = {"geometry": {"type": "mesh", "fileName": str(obj), "transform": {"type": "translate", "vector": {"x": 0, "y": 0, "z": 0}}},
+            "material": {"type": "plastic", "ior": 1.5, "cd": {"type": "flat", "color": {"r": 1, "g": 0.8, "b": 0.6}}}}
+    scene = {"width": n, "height": n, "maxDepth": 2,
+             "camera": {"position": dict(zip("xyz", pos)), "target": dict(zip("xyz", target)), "up": {"x": 0, "y": 1, "z": 0},
+                        "projection": {"type": "orthographic", "fovy": 1.0, "width": 2, "height": 2, "near": 0.1}},
+             "scene": {"objects": [mesh], "lights": [{"type": "directional", "direction": {"x": -0.2, "y": 0.5, "z": -1.0}, "color": {"r": 1, "g": 1, "b": 1}},
+                                                     {"type": "point", "position": {"x": 0.5, "y": 0.5, "z": -4.0}, "color": {"r": 40, "g": 40, "b": 40}, "radius": 0.2}]}}
+    p = tmp_path / "s.json"
+    p.write_text(json.dumps(scene))
+    want, ost = oracle_image(str(p))
+    got, st = rayhs_amd.ray_trace_file(str(p), flags=L.FLAG_COUNT)
+    exh, _ = rayhs_amd.ray_trace_file(str(p), flags=L.FLAG_COUNT | L.FLAG_EXHAUSTIVE)
+    assert np.array_equal(exh, want)
+    assert np.array_equal(got, want), (np.abs(got - want).max(), int((got != want).any(axis=2).sum()))
+    assert st["rays"] == ost["rays"] and (want > 0).any(axis=2).mean() > 0.9     # the field really is hit everywhere
