@@ -427,3 +427,19 @@ def test_rays_through_mesh_vertices_and_edges(tmp_path):
     assert np.array_equal(exh, want)
     assert np.array_equal(got, want), (np.abs(got - want).max(), int((got != want).any(axis=2).sum()))
     assert st["rays"] == ost["rays"] and (want > 0).any(axis=2).mean() > 0.9     # the field really is hit everywhere
+
+
+@pytest.mark.parametrize("dist", [3.0, 300.0, 30000.0])
+def test_camera_far_from_a_small_mesh(tmp_path, dist):
+    # the fp32 culling structure works in mesh-centred coordinates with an explicit margin for the rounding of a
+    # far-away origin; results must not depend on it
+    torus = {"geometry": {"type": "mesh", "fileName": "data/torus.obj", "transform": {"type": "sequence", "transforms": [
+        {"type": "scale", "vector": {"x": 0.5, "y": 0.5, "z": 0.5}}, {"type": "rotateX", "angle": 0.9},
+        {"type": "translate", "vector": {"x": 0.2, "y": -0.1, "z": 0.3}}]}},
+        "material": {"type": "plastic", "ior": 1.6, "cd": {"type": "flat", "color": {"r": 1, "g": 0.6, "b": 0.3}}}}
+    jd = json.loads(_scene_json([torus, FLOOR], [DIR, PT], w=40, h=30, depth=2))
+    jd["camera"]["position"] = {"x": 0.3 * dist, "y": 0.2 * dist, "z": -dist}
+    jd["camera"]["projection"]["fovy"] = 0.9272952180016123 * dist / 3.0    # keep the object in frame (f ~ h / fovy)
+    got, want, st, ost = _both(json.dumps(jd), tmp_path)
+    assert np.array_equal(got, want) and st["rays"] == ost["rays"]
+    assert (want > 0).any(axis=2).sum() > 50
