@@ -445,7 +445,12 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     variant = (p->flags & RAYHS_FLAG_EXHAUSTIVE) ? 2 : (p->flags & RAYHS_FLAG_COUNT) ? 1 : (s->d.n_fnodes < 65536 && s->d.n_nodes < 65536 ? 0 : 3);
     dp.stack_cap = std::max(std::max(s->tree_depth, s->fast_depth) + 2, 4);  // either tree may be walked (trace_kernel.hip)
     const int entry = exact ? stack_entry_bytes_exact(variant) : stack_entry_bytes_fast(variant);
-    lds = (size_t)CTX_SLOTS * TRACE_BLOCK * sizeof(double) + (size_t)dp.stack_cap * TRACE_BLOCK * (size_t)entry;
+    // LDS per workgroup: context slots + stack.  160 KiB per CU / 4 workgroups = 40 KiB each; if the stack
+    // leaves room, three more context slots keep the light term in LDS instead of the global workspace.
+    const size_t stack_bytes = (size_t)dp.stack_cap * TRACE_BLOCK * (size_t)entry;
+    dp.ctx_slots = CTX_SLOTS;
+    if ((size_t)(CTX_SLOTS + 3) * TRACE_BLOCK * sizeof(double) + stack_bytes <= 40 * 1024) dp.ctx_slots = CTX_SLOTS + 3;
+    lds = (size_t)dp.ctx_slots * TRACE_BLOCK * sizeof(double) + stack_bytes;
     if (lds > 160 * 1024) return set_error(RAYHS_ERR_UNSUPPORTED, "tree depth %d needs %zu B of LDS per workgroup (limit 160 KiB)", dp.stack_cap - 2, lds);
     // persistent grid: as many workgroups as the chip keeps resident
     int *cache = s->grid_cache[exact ? 1 : 0][variant];

@@ -119,6 +119,7 @@ struct DParams {
     int32_t out_format;
     int32_t tiles_x, n_tiles;         // 8x8-pixel tiles over (width x n_rows)
     int32_t stack_cap;                // per-lane LDS stack entries
+    int32_t ctx_slots;                // per-lane LDS context doubles: CTX_SLOTS, or CTX_SLOTS + 3 (light term too) when it fits
     int32_t frame_stride;             // threads in the grid (workspace stride)
     double *sbuf;                     // spp > 1: per-sample radiance, 3 doubles per (pixel, sample)
 };

@@ -602,14 +602,14 @@ DEV int fslot(int level, int s) { return LANE_SLOTS + level * FRAME_SLOTS + s; }
 
 // ---- LDS context slots (12 doubles per lane) ----
 enum : int { CX_P = 0, CX_N = 3, CX_CD = 6, CX_A = 9, CX_TERM = 12, CX_V = 15 };
-constexpr bool kWideCtx = CTX_SLOTS >= 18;
+constexpr bool kViewInLds = CTX_SLOTS >= 18;  // (development option; the light term moves to LDS at run time, DParams.ctx_slots)
 DEV void cx_store3(lds_dptr cx, int slot, V3 v) { cx[slot * TRACE_BLOCK] = v.x; cx[(slot + 1) * TRACE_BLOCK] = v.y; cx[(slot + 2) * TRACE_BLOCK] = v.z; }
 DEV V3 cx_load3(lds_dptr cx, int slot) { return mk(cx[slot * TRACE_BLOCK], cx[(slot + 1) * TRACE_BLOCK], cx[(slot + 2) * TRACE_BLOCK]); }
 
-#define PARK_V(v) do { if (kWideCtx) cx_store3(cx, CX_V, v); else ws_store3(ws, stride, LS_V, v); } while (0)
-#define LOAD_V() (kWideCtx ? cx_load3(cx, CX_V) : ws_load3(ws, stride, LS_V))
-#define PARK_TERM(v) do { if (kWideCtx) cx_store3(cx, CX_TERM, v); else ws_store3(ws, stride, LS_TERM, v); } while (0)
-#define LOAD_TERM() (kWideCtx ? cx_load3(cx, CX_TERM) : ws_load3(ws, stride, LS_TERM))
+#define PARK_V(v) do { if (kViewInLds) cx_store3(cx, CX_V, v); else ws_store3(ws, stride, LS_V, v); } while (0)
+#define LOAD_V() (kViewInLds ? cx_load3(cx, CX_V) : ws_load3(ws, stride, LS_V))
+#define PARK_TERM(v) do { if (term_in_lds) cx_store3(cx, CX_TERM, v); else ws_store3(ws, stride, LS_TERM, v); } while (0)
+#define LOAD_TERM() (term_in_lds ? cx_load3(cx, CX_TERM) : ws_load3(ws, stride, LS_TERM))
 
 template <bool EXH, bool COUNT, typename StackT>
 static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DParams &prm, void *out,
@@ -622,7 +622,8 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     for (int i = 0; i < 16; i++) cnt.c[i] = 0;
     lds_dptr cx = (lds_dptr)lds + tid;                                                  // context column
     typedef StackT __attribute__((address_space(3))) *stack_ptr;
-    stack_ptr stk = (stack_ptr)((lds_dptr)lds + CTX_SLOTS * TRACE_BLOCK) + tid;          // stack column
+    stack_ptr stk = (stack_ptr)((lds_dptr)lds + prm.ctx_slots * TRACE_BLOCK) + tid;      // stack column
+    const bool term_in_lds = prm.ctx_slots >= 15;  // wave-uniform: the launcher grants 3 more slots when LDS has room
     Tracer<EXH, COUNT, StackT> tr(sc, stk, cnt);
     double *ws = frames + gtid;
     const int stride = prm.frame_stride;
