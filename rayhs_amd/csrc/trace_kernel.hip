@@ -13,40 +13,41 @@
 //   lightAt, fresnel, diffuse, colorAt      src/Light.hs:12-17, src/Material.hs:22-33, src/ColorMap.hs:18-58
 //
 // How it runs here (not how the reference runs):
-//   * Persistent waves: a fixed grid sized to the chip; each 64-lane wave draws
-//     pixels (in 8x8-tile order) from one atomic ticket counter into a wave-local
-//     pool and refills a lane the moment its pixel is finished (__ballot /
-//     popcount ranking), until the frame is done.
-//   * The recursion of irradiance/specular is an explicit per-lane state
-//     machine.  Every lane, whatever its shading state, funnels into ONE scene
-//     query site per iteration, so primary, shadow, reflection and refraction
-//     rays of different pixels share the traversal loop of a wave.
-//   * Mesh traversal uses the BVH of bvh_build.cpp: 64-byte nodes holding both
-//     children's boxes as conservative fp32, a per-lane stack of inner-node
-//     indices in LDS (level-major: bank-conflict free), nearest child first,
-//     pruning against the closest hit so far, any-hit exit for shadow queries,
-//     and a while-while loop that postpones leaves so that the fp64 triangle
-//     tests run with many lanes active.  Boxes only decide which triangles are
-//     tested; the winner is the reference's because every triangle test is the
-//     reference's fp64 Moller-Trumbore and ties are resolved by its rule (first
-//     triangle in a leaf, right-most leaf, first scene object).
-//   * The exhaustive kernels instead walk the reference's own tree (fp64
-//     boxes, both children always) and visit exactly its node set.
-//   * Everything that enters a result is fp64 like the reference.  Built twice:
-//     "exact" (-ffp-contract=off, same operations as the reference/oracle) and
-//     "fast" (fused multiply-add allowed).
-//   * To run 4 waves per SIMD the kernel must fit 128 VGPRs: the shading context
-//     of a hit (p, n, cd, A: 12 doubles per lane) is parked in LDS across shadow
-//     and exit queries; the view direction, the sample sum and the continuation
-//     frames of suspended irradiance calls live in a global workspace (slot-major
-//     so lanes coalesce).
+//   * Persistent waves: a fixed grid sized to the chip.  Work items are (pixel, sample) pairs in
+//     Morton order inside 8x8-pixel tiles; a wave draws 64 consecutive items from one atomic ticket
+//     (requested one chunk ahead) and refills as a whole, so its lanes hold the samples of the same few
+//     pixels and stay in lock-step.  With spp > 1 each sample's radiance goes to a sample buffer and
+//     rayhs_resolve folds them in sample order (the reference's foldl).
+//   * The recursion of irradiance/specular is an explicit per-lane state machine.  Every lane, whatever
+//     its shading state, funnels into ONE scene query site per iteration, so primary, shadow,
+//     reflection and refraction rays share the traversal loop of a wave.
+//   * Mesh traversal uses the BVH of bvh_build.cpp: 32-byte nodes holding both children's boxes as
+//     16-bit grid coordinates (one fused multiply-add per slab plane, culling only), a per-lane stack
+//     of inner-node indices in LDS (level-major: bank-conflict free), nearest child first, pruning
+//     against the closest hit so far, any-hit exit for shadow queries, and a branch-free while-while
+//     loop that postpones leaves so that the fp64 triangle tests run with many lanes active.  Boxes
+//     only decide which triangles are tested; the winner is the reference's because every triangle test
+//     is the reference's fp64 Moller-Trumbore and ties are resolved by its rule (first triangle in a
+//     leaf, right-most leaf, first scene object).  Where the reference's own fp64 boxes are NOT a
+//     conservative cull its behaviour is replayed: rays with a (near-)zero direction component walk the
+//     reference tree (meshes_reference), near-edge hits are checked against the reference's box path
+//     (reference_path_admits).
+//   * The exhaustive kernels walk the reference's own tree for every ray (fp64 boxes, both children
+//     always) and visit exactly its node set.
+//   * Everything that enters a result is fp64 like the reference.  Built twice: "exact"
+//     (-ffp-contract=off, same operations as the reference/oracle, the default) and "fast" (fused
+//     multiply-add allowed, RAYHS_FLAG_FMA).
+//   * To run 4 waves per SIMD the kernel must fit 128 VGPRs: the shading context of a hit (p, n, cd, A
+//     and, when LDS has room, the light term) is parked in LDS across shadow and exit queries; the view
+//     direction and the continuation frames of suspended irradiance calls live in a global workspace
+//     (slot-major so lanes coalesce).
+// Development switches: RAYHS_PROFILE_LOOPS / RAYHS_PROFILE_TIME (diagnostic builds with trip counters
+// or s_memtime stamps, read with RAYHS_DEBUG_COUNTERS=1), RAYHS_SLICE_MIN / RAYHS_REFILL_MIN /
+// RAYHS_CHUNK (scheduling experiments; the defaults are the measured optimum).
 #include <hip/hip_runtime.h>
 
 #include "device_scene.h"
 
-#ifndef RAYHS_FP32_ROOT
-#define RAYHS_FP32_ROOT 1  // 1: conservative fp32 root cull; 0: the reference's exact fp64 root test
-#endif
 #ifndef RAYHS_SLICE_MIN
 #define RAYHS_SLICE_MIN 0   // leave the traversal loop when fewer lanes than this are still traversing (0: never early)
 #endif
