@@ -309,13 +309,15 @@ struct Tracer {
         double b = 2.0 * dot(r.d, oc);
         double c = dot(oc, oc) - s.r2;
         double delta = b * b - 4.0 * a * c;
-        if (delta < 0.0) return false;
+        // guards of src/Geometry.hs:81-85 in order: delta < 0 -> miss; t0 > 0 -> t0; t1 > 0 -> t1; else miss.
+        // Both roots are formed without branching (a NaN from sqrt of a negative delta is masked by the guard).
         double sq = sqrt(delta);
         double t0 = 0.5 * ((-b) - sq) / a;
-        if (t0 > 0) { t = t0; return true; }
         double t1 = 0.5 * ((-b) + sq) / a;
-        if (t1 > 0) { t = t1; return true; }
-        return false;
+        const bool ok = !(delta < 0.0);
+        const bool use0 = t0 > 0, use1 = t1 > 0;
+        t = use0 ? t0 : t1;
+        return ok && (use0 || use1);
     }
 
     // rayInterBox (src/KDTree.hs:39-56); returns pass and tmin
@@ -400,27 +402,40 @@ struct Tracer {
         bool occluded = false;
         if (active) { bt = __builtin_inf(); bu = 0; bv = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; }
 
-        // ---- planes and spheres: wave-uniform loops, scene constants via scalar loads
-        for (int i = 0; i < sc.n_planes; i++) {
+        // ---- planes and spheres: wave-uniform loops, scene constants via scalar loads.  The per-lane
+        // decisions are predicated selects, and the only branches are wave-level (ballot): nested per-lane
+        // ifs cost more scalar exec-mask bookkeeping here than the arithmetic they guard.
+        const unsigned long long wave_active = __ballot(active);
+        const unsigned long long wave_shadow = __ballot(active && shadow);
+        for (int i = 0; i < sc.n_planes && wave_active != 0ull; i++) {
             const auto &pl = as_const(sc.planes)[i];
-            if (!active || (shadow && !EXH && (occluded || !pl.occluder))) continue;
-            if (COUNT) cnt.c[CNT_PRIMS]++;
+            // outside the exhaustive kernels a shadow query skips Emmit objects and stops at its first occluder
+            const bool consider = active && (EXH || !(shadow && (occluded || !pl.occluder)));
+            if (__ballot(consider) == 0ull) continue;
+            if (COUNT && consider) cnt.c[CNT_PRIMS]++;
             double t;
-            if (plane_t(pl, r, t)) {
-                if (shadow) { if (pl.occluder) occluded = occluded || in_front(r, t, point_light, light_d2); }
-                else if (t < bt || (t == bt && pl.obj < bobj)) { bt = t; bobj = pl.obj; bprim = i; }
+            const bool hit = plane_t(pl, r, t) && consider;
+            if (wave_shadow != 0ull && __ballot(hit && shadow) != 0ull) {
+                const bool front = in_front(r, t, point_light, light_d2);
+                occluded = occluded || (hit && shadow && pl.occluder != 0 && front);
             }
+            const bool better = hit && !shadow && (t < bt || (t == bt && pl.obj < bobj));
+            bt = better ? t : bt; bobj = better ? pl.obj : bobj; bprim = better ? i : bprim;
         }
         const double a = dot(r.d, r.d);
-        for (int i = 0; i < sc.n_spheres; i++) {
+        for (int i = 0; i < sc.n_spheres && wave_active != 0ull; i++) {
             const auto &s = as_const(sc.spheres)[i];
-            if (!active || (shadow && !EXH && (occluded || !s.occluder))) continue;
-            if (COUNT) cnt.c[CNT_PRIMS]++;
-            double t;
-            if (sphere_t(s, r, a, t)) {
-                if (shadow) { if (s.occluder) occluded = occluded || in_front(r, t, point_light, light_d2); }
-                else if (t < bt || (t == bt && s.obj < bobj)) { bt = t; bobj = s.obj; bprim = -(i + 2); }
+            const bool consider = active && (EXH || !(shadow && (occluded || !s.occluder)));
+            if (__ballot(consider) == 0ull) continue;
+            if (COUNT && consider) cnt.c[CNT_PRIMS]++;
+            double t = 0;
+            const bool hit = consider && sphere_t(s, r, a, t);
+            if (wave_shadow != 0ull && __ballot(hit && shadow) != 0ull) {
+                const bool front = in_front(r, t, point_light, light_d2);
+                occluded = occluded || (hit && shadow && s.occluder != 0 && front);
             }
+            const bool better = hit && !shadow && (t < bt || (t == bt && s.obj < bobj));
+            bt = better ? t : bt; bobj = better ? s.obj : bobj; bprim = better ? -(i + 2) : bprim;
         }
         if (sc.n_meshes > 0) {
             // The reference's slab test multiplies by 1/d: with a zero direction component and a box plane
