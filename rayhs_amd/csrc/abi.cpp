@@ -47,7 +47,8 @@ static int set_error(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return set_error(RAYHS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-static constexpr int kTicketSlots = 64;
+static constexpr int kTicketSlots = 64;    // uint64 tickets per launch: 8 range counters, each on its own 64-byte line
+static constexpr int kTicketRings = 8;    // launches in flight may overlap on different streams
 
 struct rayhs_scene {
     int device = 0;
@@ -363,7 +364,7 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
     s->d.n_tris = d.n_tris;
     s->d.n_fnodes = (int)fnodes.size();
     void *p = nullptr;
-    if (hipMalloc(&p, sizeof(unsigned long long) * kTicketSlots) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(tickets) failed"));
+    if (hipMalloc(&p, sizeof(unsigned long long) * kTicketSlots * kTicketRings) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(tickets) failed"));
     s->tickets = (unsigned long long *)p;
     if (hipMalloc(&p, sizeof(unsigned long long) * CNT_SLOTS) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(counters) failed"));
     s->counters = (unsigned long long *)p;
@@ -500,8 +501,8 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
     if (dp.n_tiles == 0) return RAYHS_OK;
     HIP_TRY(hipSetDevice(s->device));
     if ((rc = ensure_workspace(s, dp))) return rc;
-    unsigned long long *ticket = s->tickets + (s->next_ticket++ % kTicketSlots);
-    HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long), st));
+    unsigned long long *ticket = s->tickets + (size_t)(s->next_ticket++ % kTicketRings) * kTicketSlots;
+    HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long) * kTicketSlots, st));
     dp.sbuf = dp.spp > 1 ? s->sbuf : nullptr;
     if (e0) HIP_TRY(hipEventRecord(e0, st));
     hipError_t e = exact ? launch_trace_exact(variant, grid, lds, st, s->d, dc, dp, d_out, (unsigned long long *)d_counters, ticket, s->frames)

@@ -14,8 +14,8 @@
 //
 // How it runs here (not how the reference runs):
 //   * Persistent waves: a fixed grid sized to the chip.  Work items are (pixel, sample) pairs in
-//     Morton order inside 8x8-pixel tiles; a wave draws 64 consecutive items from one atomic ticket
-//     (requested one chunk ahead) and refills as a whole, so its lanes hold the samples of the same few
+//     Morton order inside 8x8-pixel tiles; a wave draws 64 consecutive items from the ticket counter of
+//     its XCD's band of the frame (8 bands, requested one chunk ahead, next band when dry) and refills as a whole, so its lanes hold the samples of the same few
 //     pixels and stay in lock-step.  With spp > 1 each sample's radiance goes to a sample buffer and
 //     rayhs_resolve folds them in sample order (the reference's foldl).
 //   * The recursion of irradiance/specular is an explicit per-lane state machine.  Every lane, whatever
@@ -665,8 +665,17 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     const unsigned long long total_items = (unsigned long long)prm.n_tiles * 64ull * (unsigned long long)prm.spp;
     unsigned long long pool_next = 0, pool_end = 0;
     bool exhausted = false;
-    unsigned long long ticket_ahead = 0;  // lane 0: ticket requested ahead of need
-    if (lane == 0) ticket_ahead = atomicAdd(ticket, (unsigned long long)kChunk);
+    // XCD-aware work distribution: the item space is cut into 8 contiguous ranges (bands of tiles), each with
+    // its own ticket counter on its own 64-byte line.  A wave starts on the range of the XCD it runs on
+    // (HW_REG_XCC_ID), so one XCD's L2 mostly sees one part of the frame and of the BVH; when its range is
+    // used up it moves on to the next one, so the split only steers locality, never the balance.
+    constexpr int kRanges = 8;
+    const unsigned long long per_range = ((total_items + (unsigned long long)kRanges * kChunk - 1) / ((unsigned long long)kRanges * kChunk)) * kChunk;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    int range = (int)(xcc & (kRanges - 1)), ranges_done = 0;
+    unsigned long long ticket_ahead = 0;  // lane 0: ticket of `range` requested ahead of need
+    if (lane == 0) ticket_ahead = atomicAdd(ticket + range * 8, (unsigned long long)kChunk);
 
     TIME_DECL;
 #ifdef RAYHS_PROFILE_TIME
@@ -677,19 +686,29 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         if (__popcll(idle) < RAYHS_REFILL_MIN) idle = 0ull;
         while (idle != 0ull && !exhausted) {  // wave-uniform
             if (pool_next == pool_end) {
-                // the ticket for this chunk was requested one refill ago; request the next one now, so that the
-                // atomic's round trip (microseconds) runs beside the chunk's work instead of in front of it
+                // the ticket for this chunk was requested one refill ago; the next one is requested below, so that
+                // the atomic's round trip (microseconds) runs beside the chunk's work instead of in front of it
                 unsigned long long c = ticket_ahead;
-                if (lane == 0) ticket_ahead = atomicAdd(ticket, (unsigned long long)kChunk);
-                c = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(c >> 32)) << 32) |
-                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)c);
-                pool_next = c;
+                while (true) {  // wave-uniform; more than one pass only when a range runs dry (<= 8 times per wave)
+                    c = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(c >> 32)) << 32) |
+                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)c);
+                    const unsigned long long start = (unsigned long long)range * per_range;
+                    const unsigned long long size = start >= total_items ? 0ull : (total_items - start < per_range ? total_items - start : per_range);
+                    if (c < size) {
+                        pool_next = start + c;
+                        pool_end = c + kChunk < size ? start + c + kChunk : start + size;
+                        break;
+                    }
+                    if (++ranges_done == kRanges) { exhausted = true; break; }
+                    range = (range + 1) & (kRanges - 1);
+                    if (lane == 0) c = atomicAdd(ticket + range * 8, (unsigned long long)kChunk);
+                }
+                if (exhausted) break;
+                if (lane == 0) ticket_ahead = atomicAdd(ticket + range * 8, (unsigned long long)kChunk);
 #ifdef RAYHS_PROFILE_TIME
-                if (c < total_items) cnt.c[7]++;  // chunks this wave obtained (lane-0 value is reduced)
-                if (c < total_items && cnt.c[6] == 0) cnt.c[6] = 1;  // waves that obtained any work
+                cnt.c[7]++;  // chunks this wave obtained (lane-0 value is reduced)
+                if (cnt.c[6] == 0) cnt.c[6] = 1;  // waves that obtained any work
 #endif
-                pool_end = c + kChunk < total_items ? c + kChunk : total_items;
-                if (c >= total_items) { exhausted = true; break; }
             }
             const unsigned avail = (unsigned)(pool_end - pool_next);
             const unsigned rank = (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
