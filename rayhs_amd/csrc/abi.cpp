@@ -438,6 +438,8 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     dp.row0 = p->row0; dp.n_rows = rows;
     dp.stripe_rows = p->stripe_rows; dp.stripe_rank = p->stripe_rank; dp.stripe_count = p->stripe_count;
     dp.out_format = p->out_format;
+    // samples of a pixel are folded inside the wave when they all sit in one 64-item chunk (trace_kernel.hip)
+    dp.wave_resolve = (p->spp > 1 && 64 % p->spp == 0 && !std::getenv("RAYHS_NO_WAVE_RESOLVE")) ? 1 : 0;
     dp.tiles_x = (p->width + 7) / 8;
     dp.n_tiles = dp.tiles_x * ((rows + 7) / 8);
     exact = (p->flags & RAYHS_FLAG_FMA) == 0;
@@ -480,7 +482,7 @@ static int ensure_workspace(const rayhs_scene *s, const DParams &dp) {
         s->frames = (double *)p; s->frames_bytes = need;
     }
     // spp > 1: one radiance triple per (pixel, sample), folded in sample order by rayhs_resolve
-    size_t sneed = dp.spp > 1 ? (size_t)dp.n_rows * (size_t)dp.width * (size_t)dp.spp * 3 * sizeof(double) : 0;
+    size_t sneed = dp.spp > 1 && !dp.wave_resolve ? (size_t)dp.n_rows * (size_t)dp.width * (size_t)dp.spp * 3 * sizeof(double) : 0;
     if (sneed > s->sbuf_bytes) {
         if (s->sbuf) HIP_TRY(hipFree(s->sbuf));
         s->sbuf = nullptr; s->sbuf_bytes = 0;
@@ -503,13 +505,13 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
     if ((rc = ensure_workspace(s, dp))) return rc;
     unsigned long long *ticket = s->tickets + (size_t)(s->next_ticket++ % kTicketRings) * kTicketSlots;
     HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long) * kTicketSlots, st));
-    dp.sbuf = dp.spp > 1 ? s->sbuf : nullptr;
+    dp.sbuf = dp.spp > 1 && !dp.wave_resolve ? s->sbuf : nullptr;
     if (e0) HIP_TRY(hipEventRecord(e0, st));
     hipError_t e = exact ? launch_trace_exact(variant, grid, lds, st, s->d, dc, dp, d_out, (unsigned long long *)d_counters, ticket, s->frames)
                          : launch_trace_fast(variant, grid, lds, st, s->d, dc, dp, d_out, (unsigned long long *)d_counters, ticket, s->frames);
     if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "trace kernel launch failed: %s", hipGetErrorString(e));
     if (e1) HIP_TRY(hipEventRecord(e1, st));
-    if (dp.spp > 1) {
+    if (dp.spp > 1 && !dp.wave_resolve) {
         e = exact ? launch_resolve_exact(st, s->sbuf, d_out, dp.n_rows * dp.width, dp.spp, dp.out_format)
                   : launch_resolve_fast(st, s->sbuf, d_out, dp.n_rows * dp.width, dp.spp, dp.out_format);
         if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "resolve kernel launch failed: %s", hipGetErrorString(e));

@@ -122,6 +122,8 @@ struct DParams {
     int32_t ctx_slots;                // per-lane LDS context doubles: CTX_SLOTS, or CTX_SLOTS + 3 (light term too) when it fits
     int32_t frame_stride;             // threads in the grid (workspace stride)
     double *sbuf;                     // spp > 1: per-sample radiance, 3 doubles per (pixel, sample)
+    int32_t wave_resolve;             // 1: spp divides 64, samples are folded inside the wave (no sample buffer)
+    int32_t pad_;
 };
 
 // counters[] slots

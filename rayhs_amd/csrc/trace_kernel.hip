@@ -674,6 +674,11 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
     int range = (int)(xcc & (kRanges - 1)), ranges_done = 0;
+    // In-wave resolve (prm.wave_resolve: spp divides 64 and the wave refills as a whole): the samples of a pixel
+    // then sit in consecutive lanes of one chunk, finished samples wait in the lane's LDS context slot, and when the
+    // whole chunk is done the lane holding sample 0 adds them up in sample order (the reference's foldl) and writes
+    // the pixel -- no sample buffer, no resolve pass.
+    bool chunk_pending = false, item_valid = false;
     unsigned long long ticket_ahead = 0;  // lane 0: ticket of `range` requested ahead of need
     if (lane == 0) ticket_ahead = atomicAdd(ticket + range * 8, (unsigned long long)kChunk);
 
@@ -683,6 +688,16 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
 #endif
     while (true) {
         unsigned long long idle = __ballot(state == ST_DONE);
+        if (prm.wave_resolve && chunk_pending && idle == ~0ull) {
+            if (item_valid && sample == 0) {
+                V3 sum = mk(0, 0, 0);
+                for (int k = 0; k < prm.spp; k++)  // foldl (+) black, samples in order (src/RayHs.hs:169-171)
+                    sum = add(sum, mk(cx[CX_A * TRACE_BLOCK + k], cx[(CX_A + 1) * TRACE_BLOCK + k], cx[(CX_A + 2) * TRACE_BLOCK + k]));
+                store_pixel(out, prm.out_format, (size_t)lrow * (size_t)prm.width + (size_t)px, scl(1.0 / (double)prm.spp, sum));
+            }
+            chunk_pending = false;
+            item_valid = false;
+        }
         if (__popcll(idle) < RAYHS_REFILL_MIN) idle = 0ull;
         while (idle != 0ull && !exhausted) {  // wave-uniform
             if (pool_next == pool_end) {
@@ -723,7 +738,8 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                 // wave holds at once are neighbours in both directions
                 px = tx * 8 + ((within & 1) | ((within >> 1) & 2) | ((within >> 2) & 4));
                 lrow = ty * 8 + (((within >> 1) & 1) | ((within >> 2) & 2) | ((within >> 3) & 4));
-                if (px < prm.width && lrow < prm.n_rows) {
+                item_valid = px < prm.width && lrow < prm.n_rows;
+                if (item_valid) {
                     // local row -> image row (stripe interleave, include/rayhs.h)
                     int s_local = lrow / prm.stripe_rows, in_stripe = lrow - s_local * prm.stripe_rows;
                     yrow = prm.row0 + (s_local * prm.stripe_count + prm.stripe_rank) * prm.stripe_rows + in_stripe;
@@ -731,6 +747,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                 }
             }
             const unsigned long long took = __ballot(take);
+            chunk_pending = chunk_pending || took != 0ull;
             pool_next += (unsigned long long)__popcll(took);
             idle &= ~took;
         }
@@ -907,7 +924,9 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
             while (step == A_RETURN) {
                 if (fsp == 0) {
                     const size_t pix = (size_t)lrow * (size_t)prm.width + (size_t)px;
-                    if (prm.spp > 1) {
+                    if (prm.wave_resolve) {
+                        cx_store3(cx, CX_A, result);  // waits in LDS for the in-wave resolve (the A slot is free now)
+                    } else if (prm.spp > 1) {
                         // one sample of distributedTracePixel (src/RayHs.hs:173-183); rayhs_resolve folds them in order
                         double *sb = prm.sbuf + (pix * (size_t)prm.spp + (size_t)sample) * 3;
                         sb[0] = result.x; sb[1] = result.y; sb[2] = result.z;

@@ -74,6 +74,20 @@ def test_bit_exact_against_oracle_at_other_sizes(scene, w, h, spp):
     assert st["rays"] == ost["rays"]
 
 
+@pytest.mark.parametrize("spp", [2, 3, 5, 8, 16, 32, 64, 96])
+def test_sample_fold_is_in_sample_order_for_every_spp(spp, monkeypatch):
+    # spp dividing 64 is folded inside the wave, anything else through the sample buffer + resolve pass;
+    # both must equal the reference's foldl over samples (src/RayHs.hs:169-171), with and without counters
+    scene = "data/transform.json"
+    want, _ = oracle_image(scene, width=41, height=29, spp=spp)
+    for flags in (0, L.FLAG_COUNT):
+        got, _ = rayhs_amd.ray_trace_file(scene, width=41, height=29, spp=spp, flags=flags)
+        assert np.array_equal(got, want), flags
+    monkeypatch.setenv("RAYHS_NO_WAVE_RESOLVE", "1")  # development knob: force the buffer path
+    got, _ = rayhs_amd.ray_trace_file(scene, width=41, height=29, spp=spp)
+    assert np.array_equal(got, want)
+
+
 def test_exhaustive_mode_visits_exactly_the_reference_node_set():
     # under exhaustive traversal the work counters equal the oracle's
     O.lib().orc_set_shadow_exhaustive(1)
