@@ -81,6 +81,9 @@ static int check_desc(const rayhs_scene_desc *d, int &tree_depth) {
     if (!d) return set_error(RAYHS_ERR_INVALID, "scene description is NULL");
     if (d->n_objects < 0 || d->n_planes < 0 || d->n_spheres < 0 || d->n_meshes < 0 || d->n_nodes < 0 || d->n_tris < 0 || d->n_lights < 0)
         return set_error(RAYHS_ERR_INVALID, "negative count in scene description");
+    // the kernels address records as base + 32-bit byte offset (largest record: 128 B per triangle, 64 B per node)
+    if (d->n_tris > (1 << 25) || d->n_nodes > (1 << 25))
+        return set_error(RAYHS_ERR_INVALID, "scene too large: at most 2^25 triangles and tree nodes are supported");
     for (int i = 0; i < d->n_objects; i++) {
         int k = d->obj_geom_kind[i], g = d->obj_geom_index[i];
         int lim = k == RAYHS_GEOM_PLANE ? d->n_planes : k == RAYHS_GEOM_SPHERE ? d->n_spheres : k == RAYHS_GEOM_MESH ? d->n_meshes : -1;
@@ -194,7 +197,7 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
     std::vector<DTriAttr> fattrs;
     std::vector<int> mesh_froot((size_t)d.n_meshes, FNODE_NONE), mesh_tri_base((size_t)d.n_meshes, 0);
     std::vector<double> mesh_center(3 * (size_t)d.n_meshes, 0.0);
-    std::vector<float> mesh_fbox(12 * (size_t)d.n_meshes, 0.0f);
+    std::vector<float> mesh_fbox(6 * (size_t)d.n_meshes, 0.0f);
     int fast_depth = 0;
     for (int m = 0; m < d.n_meshes; m++) {
         std::vector<int> ids;       // triangle indices in reference DFS order
@@ -225,27 +228,19 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
         double ext = 0, ctr[3];
         for (int c = 0; c < 3; c++) { ctr[c] = 0.5 * (bvh.lo[c] + bvh.hi[c]); ext = std::max(ext, bvh.hi[c] - bvh.lo[c]); mesh_center[3 * (size_t)m + (size_t)c] = ctr[c]; }
         // mesh bounds relative to the mesh centre, rounded outward and inflated by 2^-18 of the mesh extent
-        // (64x the fp32 rounding error of a ray origin inside them, trace_kernel.hip): root cull + grid frame
+        // (64x the fp32 rounding error of a ray origin inside them, trace_kernel.hip): root cull
         const double infl = std::max(ext, 1e-300) * (1.0 / 262144.0);
-        float *mf = &mesh_fbox[12 * (size_t)m];  // flo[3], fhi[3], glo[3], gstep[3]
+        float *mf = &mesh_fbox[6 * (size_t)m];  // flo[3], fhi[3]
         for (int c = 0; c < 3; c++) {
             mf[c] = round_down_f32((bvh.lo[c] - ctr[c]) - infl);
             mf[3 + c] = round_up_f32((bvh.hi[c] - ctr[c]) + infl);
-            mf[6 + c] = mf[c];
-            // step: (fhi - flo) / 65535 rounded up, so that 65535 steps reach past fhi
-            mf[9 + c] = round_up_f32(((double)mf[3 + c] - (double)mf[c]) / 65535.0 * (1.0 + 1e-6));
-            if (!(mf[9 + c] > 0)) mf[9 + c] = 1e-30f;
         }
-        // node boxes: 16-bit grid coordinates, floor/ceil plus ONE extra unit outward.  The extra unit
-        // (1.5e-5 of the extent) covers every fp32 rounding in the kernel's fused slab test.
-        auto quant = [&](const double *lo, const double *hi, uint16_t *qlo, uint16_t *qhi) {
+        // node boxes: mesh-centred fp32, inflated like the mesh bounds and rounded outward; the inflation covers every
+        // fp32 rounding of the kernel's slab test (origin, reciprocal direction, one fused multiply-add per plane)
+        auto fbox32 = [&](const double *lo, const double *hi, float *b) {
             for (int c = 0; c < 3; c++) {
-                if (lo[c] <= hi[c]) {
-                    double a = std::floor(((lo[c] - ctr[c]) - (double)mf[6 + c]) / (double)mf[9 + c]) - 1.0;
-                    double b = std::ceil(((hi[c] - ctr[c]) - (double)mf[6 + c]) / (double)mf[9 + c]) + 1.0;
-                    qlo[c] = (uint16_t)std::min(65535.0, std::max(0.0, a));
-                    qhi[c] = (uint16_t)std::min(65535.0, std::max(0.0, b));
-                } else { qlo[c] = 65535; qhi[c] = 0; }
+                if (lo[c] <= hi[c]) { b[2 * c] = round_down_f32((lo[c] - ctr[c]) - infl); b[2 * c + 1] = round_up_f32((hi[c] - ctr[c]) + infl); }
+                else { b[2 * c] = 0; b[2 * c + 1] = 0; }  // absent child: its reference is FNODE_NONE, the box is never used
             }
         };
         // inner references index the global node array; leaf references ~((first << 3) | count) index the
@@ -254,8 +249,8 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
         for (const FNodeBuild &nb : bvh.nodes) {
             FNode fn;
             std::memset(&fn, 0, sizeof fn);
-            quant(nb.lo0, nb.hi0, fn.lo0, fn.hi0);
-            quant(nb.lo1, nb.hi1, fn.lo1, fn.hi1);
+            fbox32(nb.lo0, nb.hi0, fn.b0);
+            fbox32(nb.lo1, nb.hi1, fn.b1);
             fn.c0 = child(nb.c0); fn.c1 = child(nb.c1);
             fnodes.push_back(fn);
         }
@@ -312,10 +307,8 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
                 m.lo[c] = m.root >= 0 ? d.node_lo[3 * m.root + c] : 0;
                 m.hi[c] = m.root >= 0 ? d.node_hi[3 * m.root + c] : 0;
                 m.center[c] = mesh_center[3 * (size_t)g + (size_t)c];
-                m.flo[c] = mesh_fbox[12 * (size_t)g + (size_t)c];
-                m.fhi[c] = mesh_fbox[12 * (size_t)g + 3 + (size_t)c];
-                m.glo[c] = mesh_fbox[12 * (size_t)g + 6 + (size_t)c];
-                m.gstep[c] = mesh_fbox[12 * (size_t)g + 9 + (size_t)c];
+                m.flo[c] = mesh_fbox[6 * (size_t)g + (size_t)c];
+                m.fhi[c] = mesh_fbox[6 * (size_t)g + 3 + (size_t)c];
             }
         }
     }
@@ -474,6 +467,8 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
 
 static int ensure_workspace(const rayhs_scene *s, const DParams &dp) {
     size_t need = ((size_t)LANE_SLOTS + (size_t)std::max(dp.max_depth, 1) * FRAME_SLOTS) * (size_t)dp.frame_stride * sizeof(double);
+    if (need >= ((size_t)1 << 32) || dp.frame_stride >= (1 << 24))  // 32-bit byte offsets / 24-bit multiplies in the kernel
+        return set_error(RAYHS_ERR_INVALID, "max_depth %d needs a %zu-byte continuation workspace; the limit is 4 GiB", dp.max_depth, need);
     if (need > s->frames_bytes) {
         if (s->frames) HIP_TRY(hipFree(s->frames));
         s->frames = nullptr; s->frames_bytes = 0;

@@ -23,15 +23,16 @@ struct alignas(16) DNode {
 static constexpr int32_t DNODE_LEAF = (int32_t)0x80000000;
 
 // ---- fast traversal structure (bvh_build.cpp) ----
-// 32 B per node = two 16-byte requests per lane per visit (the L1 tag pipeline, not bandwidth, bounds a
-// divergent traversal: every 16 B a lane asks for costs it a cycle).  Both children's boxes are stored
-// as 16-bit coordinates on a per-mesh grid (DMesh.glo/gstep), rounded outward by one extra grid unit,
-// so that  t = q * (step * 1/d) + (glo - o) * 1/d  is one fused multiply-add per slab plane.
+// 64 B per node: both children's boxes as mesh-centred fp32 planes {lo.x, hi.x, lo.y, hi.y, lo.z, hi.z}, inflated
+// by 2^-18 of the mesh extent and rounded outward (abi.cpp), so that the slab test is one packed fused
+// multiply-add per axis,  t = plane * (1/d) + (-o/d),  with no decode step.  (32-byte nodes with 16-bit grid
+// coordinates were 2 % slower once the waves were coherent: 12 conversions per visit cost more than the bytes.)
 // Child reference: >= 0 inner node, < 0 leaf ~((first << 3) | count) into the BVH-ordered triangle
 // array, INT32_MIN = no child.
 struct alignas(16) FNode {
-    uint16_t lo0[3], hi0[3], lo1[3], hi1[3];
+    float b0[6], b1[6];
     int32_t c0, c1;
+    int32_t pad_[2];
 };
 static constexpr int32_t FNODE_NONE = (int32_t)0x80000000;
 
@@ -67,7 +68,6 @@ struct DMesh {
     double lo[3], hi[3];            // the reference root's box (src/KDTree.hs:84)
     double center[3];               // origin of the fp32 box coordinates
     float flo[3], fhi[3];           // bounds of the mesh in those coordinates, rounded outward and inflated
-    float glo[3], gstep[3];         // origin and step of the 16-bit grid the node boxes are stored on
 };
 struct DObject {  // Material (src/Material.hs:13-19) + ColorMap (src/ColorMap.hs:11-16) of one object
     int32_t mat_kind, cmap_kind, tex_w, tex_h;

@@ -15,14 +15,15 @@
 // How it runs here (not how the reference runs):
 //   * Persistent waves: a fixed grid sized to the chip.  Work items are (pixel, sample) pairs in
 //     Morton order inside 8x8-pixel tiles; a wave draws 64 consecutive items from the ticket counter of
-//     its XCD's band of the frame (8 bands, requested one chunk ahead, next band when dry) and refills as a whole, so its lanes hold the samples of the same few
-//     pixels and stay in lock-step.  With spp > 1 each sample's radiance goes to a sample buffer and
-//     rayhs_resolve folds them in sample order (the reference's foldl).
+//     its XCD's band of the frame (8 bands, requested one chunk ahead, next band when dry) and refills
+//     as a whole, so its lanes hold the samples of the same few pixels and stay in lock-step.  When spp
+//     divides 64 a pixel's samples sit in one chunk and are folded in sample order (the reference's
+//     foldl) inside the wave; any other spp > 1 goes through a sample buffer and rayhs_resolve.
 //   * The recursion of irradiance/specular is an explicit per-lane state machine.  Every lane, whatever
 //     its shading state, funnels into ONE scene query site per iteration, so primary, shadow,
 //     reflection and refraction rays share the traversal loop of a wave.
-//   * Mesh traversal uses the BVH of bvh_build.cpp: 32-byte nodes holding both children's boxes as
-//     16-bit grid coordinates (one fused multiply-add per slab plane, culling only), a per-lane stack
+//   * Mesh traversal uses the BVH of bvh_build.cpp: 64-byte nodes holding both children's boxes as
+//     mesh-centred fp32 planes (one packed fused multiply-add per axis, culling only), a per-lane stack
 //     of inner-node indices in LDS (level-major: bank-conflict free), nearest child first, pruning
 //     against the closest hit so far, any-hit exit for shadow queries, and a branch-free while-while
 //     loop that postpones leaves so that the fp64 triangle tests run with many lanes active.  Boxes
@@ -262,6 +263,12 @@ DEV float f32_up(double v) {  // smallest float >= v (v >= 0 here)
     return f;
 }
 
+// ---- per-lane reads of scene records: uniform base (an SGPR pair) + 32-bit byte offset, so that the load uses the
+// scalar-base addressing form instead of 64-bit per-lane pointer arithmetic (abi.cpp keeps every array < 4 GiB)
+template <typename T> DEV const T &rec(const T *base, int index) {
+    return *(const T *)((const char *)base + (unsigned)index * (unsigned)sizeof(T));
+}
+
 template <bool EXH, bool COUNT, typename StackT>
 struct Tracer {
     typedef StackT __attribute__((address_space(3))) *stack_ptr;
@@ -281,7 +288,7 @@ struct Tracer {
     int t_cur, t_sp;       // current inner node (FNODE_NONE = none), stack depth
     int t_pa, t_pb;        // postponed leaves
     int t_obj;             // scene object of the mesh being traversed
-    float t_ax, t_ay, t_az, t_bx, t_by, t_bz;  // per-plane slab coefficients of the current mesh (see qbox)
+    float t_ax, t_ay, t_az, t_bx, t_by, t_bz;  // per-plane slab coefficients of the current mesh (see pbox)
     float t_enter;                             // shift of the traversal origin along the ray
 
     __device__ __forceinline__ bool traversing() const {
@@ -366,15 +373,15 @@ struct Tracer {
         return take;
     }
 
-    // slab test of one 16-bit child box: t = q * A + B per plane (A = grid step / d, B = (grid origin - o) / d),
-    // one fused multiply-add each.  Culling only: the stored boxes carry a whole grid unit of slack.
-    __device__ __forceinline__ bool qbox(const uint16_t *lo, const uint16_t *hi, float ax, float ay, float az, float bx, float by, float bz,
-                                         float limf, float &tnear) {
-        float t1 = __builtin_fmaf((float)lo[0], ax, bx), t2 = __builtin_fmaf((float)hi[0], ax, bx);
-        float t3 = __builtin_fmaf((float)lo[1], ay, by), t4 = __builtin_fmaf((float)hi[1], ay, by);
-        float t5 = __builtin_fmaf((float)lo[2], az, bz), t6 = __builtin_fmaf((float)hi[2], az, bz);
-        float tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
-        float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    // slab test of one child box: t = plane * A + B (A = 1/d, B = -o/d), one packed fused multiply-add per axis.
+    // Culling only: the stored boxes are inflated far beyond the fp32 rounding of these operations (abi.cpp).
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ bool pbox(const float *b, float ax, float ay, float az, float bx, float by, float bz, float limf, float &tnear) {
+        const f2 x = __builtin_elementwise_fma((f2){b[0], b[1]}, (f2){ax, ax}, (f2){bx, bx});
+        const f2 y = __builtin_elementwise_fma((f2){b[2], b[3]}, (f2){ay, ay}, (f2){by, by});
+        const f2 z = __builtin_elementwise_fma((f2){b[4], b[5]}, (f2){az, az}, (f2){bz, bz});
+        float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fminf(z.x, z.y));
+        float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fmaxf(z.x, z.y));
         tnear = tn;
         return tf >= fmaxf(tn, 0.0f) && tn <= limf;
     }
@@ -466,7 +473,7 @@ struct Tracer {
                     node = (int)stack[sp * TRACE_BLOCK];
                     continue;
                 }
-                const DNode nd = sc.nodes[node];
+                const DNode nd = rec(sc.nodes, node);
                 if (COUNT) cnt.c[CNT_NODES]++;
                 double tmin;
                 int next = -1;
@@ -474,7 +481,7 @@ struct Tracer {
                     if (nd.flags & DNODE_LEAF) {
                         const int first = nd.a, last = nd.a + nd.b;
                         for (int k = first; k < last; k++) {
-                            const DTri tr = sc.tris[k];
+                            const DTri tr = rec(sc.tris, k);
                             if (COUNT) cnt.c[CNT_TRIS]++;
                             double t, u, v;
                             if (tri_test(tr, r, t, u, v)) {
@@ -508,7 +515,7 @@ struct Tracer {
         while (true) {
             // start the next mesh for lanes that have exhausted the current one
             while (t_cur == FNODE_NONE && t_pa == FNODE_NONE && t_sp == 0 && t_m < sc.n_meshes) {
-                const auto &me = as_const(sc.meshes)[t_m];
+                const auto &me = rec(sc.meshes, t_m);
                 t_m++;
                 if (me.froot == FNODE_NONE || (shadow && !me.occluder)) continue;
                 const double lim = shadow ? light_dist : bt;
@@ -528,8 +535,8 @@ struct Tracer {
                 const float sx = (float)((r.o.x + te * r.d.x) - me.center[0]);
                 const float sy = (float)((r.o.y + te * r.d.y) - me.center[1]);
                 const float sz = (float)((r.o.z + te * r.d.z) - me.center[2]);
-                t_ax = me.gstep[0] * ix; t_ay = me.gstep[1] * iy; t_az = me.gstep[2] * iz;
-                t_bx = (me.glo[0] - sx) * ix; t_by = (me.glo[1] - sy) * iy; t_bz = (me.glo[2] - sz) * iz;
+                t_ax = ix; t_ay = iy; t_az = iz;
+                t_bx = -sx * ix; t_by = -sy * iy; t_bz = -sz * iz;
                 limf = f32_up(lim - te);
                 t_obj = me.obj;
                 t_cur = me.froot;
@@ -546,27 +553,29 @@ struct Tracer {
                     if (t_cur == leader) cnt.c[14]++;
                 }
 #endif
-                const FNode nd = sc.fnodes[t_cur];
+                const FNode nd = rec(sc.fnodes, t_cur);
                 float tn0, tn1;
-                const bool h0 = qbox(nd.lo0, nd.hi0, t_ax, t_ay, t_az, t_bx, t_by, t_bz, limf, tn0) & (nd.c0 != FNODE_NONE);
-                const bool h1 = qbox(nd.lo1, nd.hi1, t_ax, t_ay, t_az, t_bx, t_by, t_bz, limf, tn1) & (nd.c1 != FNODE_NONE);
+                const bool h0 = pbox(nd.b0, t_ax, t_ay, t_az, t_bx, t_by, t_bz, limf, tn0) && nd.c0 != FNODE_NONE;
+                const bool h1 = pbox(nd.b1, t_ax, t_ay, t_az, t_bx, t_by, t_bz, limf, tn1) && nd.c1 != FNODE_NONE;
                 if (COUNT) cnt.c[CNT_NODES] += (nd.c0 != FNODE_NONE) + (nd.c1 != FNODE_NONE);
                 const bool near0 = tn0 <= tn1;
-                const bool l0 = h0 & (nd.c0 < 0), l1 = h1 & (nd.c1 < 0);    // hit leaves
-                const bool i0 = h0 & (nd.c0 >= 0), i1 = h1 & (nd.c1 >= 0);  // hit inner children
+                const bool l0 = h0 && nd.c0 < 0, l1 = h1 && nd.c1 < 0;    // hit leaves
+                const bool i0 = h0 && nd.c0 >= 0, i1 = h1 && nd.c1 >= 0;  // hit inner children
+                const int cnear = near0 ? nd.c0 : nd.c1, cfar = near0 ? nd.c1 : nd.c0;
                 // leaves are postponed, nearer one first
-                const int la = (l0 & l1) ? (near0 ? nd.c0 : nd.c1) : (l0 ? nd.c0 : nd.c1);
-                t_pa = (l0 | l1) ? la : FNODE_NONE;
-                t_pb = (l0 & l1) ? (near0 ? nd.c1 : nd.c0) : FNODE_NONE;
+                const bool both_leaves = l0 && l1, any_leaf = l0 || l1;
+                t_pa = both_leaves ? cnear : (l0 ? nd.c0 : (l1 ? nd.c1 : FNODE_NONE));
+                t_pb = both_leaves ? cfar : FNODE_NONE;
                 // inner children: descend into the nearer, push the other.  The push is an unconditional LDS
                 // write to the top-of-stack slot (kept only when sp advances) and the pop an unconditional read,
                 // so the loop body has no branches at all.
-                const bool both = i0 & i1, any_inner = i0 | i1, any_leaf = l0 | l1;
-                const int ia = both ? (near0 ? nd.c0 : nd.c1) : (i0 ? nd.c0 : nd.c1);
-                stack[t_sp * TRACE_BLOCK] = (StackT)(near0 ? nd.c1 : nd.c0);
+                const bool both = i0 && i1, any_inner = i0 || i1;
+                const int ia = both ? cnear : (i0 ? nd.c0 : nd.c1);
+                stack[t_sp * TRACE_BLOCK] = (StackT)cfar;
                 const int top = t_sp > 0 ? t_sp - 1 : 0;
-                const int popped = (int)stack[top * TRACE_BLOCK];
-                const bool pop = !any_inner & !any_leaf & (t_sp > 0);
+                int popped = (int)stack[top * TRACE_BLOCK];
+                asm volatile("" : "+v"(popped));  // keep the read unconditional: sunk into a branch it splits the loop body
+                const bool pop = !any_inner && !any_leaf && t_sp > 0;
                 t_cur = any_inner ? ia : (pop ? popped : FNODE_NONE);
                 t_sp = t_sp + (both ? 1 : 0) - (pop ? 1 : 0);
             }
@@ -577,13 +586,13 @@ struct Tracer {
                 const int ref = ~t_pa;
                 const int first = ref >> 3, n = ref & 7;  // leaf references index the BVH-ordered arrays directly
                 for (int k = first; k < first + n; k++) {
-                    const DTri tr = sc.ftris[k];
+                    const DTri tr = rec(sc.ftris, k);
                     if (COUNT) cnt.c[CNT_TRIS]++;
                     double t, u, v;
                     if (tri_test(tr, r, t, u, v)) {
                         bool admitted = true;
                         if (u < kEdgeBand || v < kEdgeBand || (u + v) > 1 - kEdgeBand)
-                            admitted = reference_path_admits(sc.nodes, sc.fattrs[k].leaf_node, r.o, r.d);
+                            admitted = reference_path_admits(sc.nodes, rec(sc.fattrs, k).leaf_node, r.o, r.d);
                         if (admitted) {
                             if (shadow) occ = occ || in_front(r, t, point_light, light_d2);
                             else if (offer(t, u, v, t_obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - (double)t_enter); }
@@ -610,10 +619,13 @@ struct Tracer {
 // ---- global per-lane workspace: LANE_SLOTS lane slots, then FRAME_SLOTS per continuation level ----
 enum : int { LS_V = 0, LS_TERM = 3 };
 enum : int { FS_KIND = 0, FS_DEPTH = 1, FS_F = 2, FS_S = 3, FS_K = 4, FS_A = 5, FS_RO = 8, FS_RD = 11 };
-DEV void ws_store(double *ws, int stride, int slot, double v) { ws[(size_t)slot * (size_t)stride] = v; }
-DEV double ws_load(const double *ws, int stride, int slot) { return ws[(size_t)slot * (size_t)stride]; }
-DEV void ws_store3(double *ws, int stride, int slot, V3 v) { ws_store(ws, stride, slot, v.x); ws_store(ws, stride, slot + 1, v.y); ws_store(ws, stride, slot + 2, v.z); }
-DEV V3 ws_load3(const double *ws, int stride, int slot) { return mk(ws_load(ws, stride, slot), ws_load(ws, stride, slot + 1), ws_load(ws, stride, slot + 2)); }
+// slot-major: slot s of lane g sits at frames[s * stride + g]; addressed as uniform base + 32-bit byte offset
+struct Workspace { double *base; unsigned stride, lane; };
+DEV double *ws_at(const Workspace &ws, int slot) { return (double *)((char *)ws.base + ((__umul24((unsigned)slot, ws.stride) + ws.lane) << 3)); }
+DEV void ws_store(const Workspace &ws, int slot, double v) { *ws_at(ws, slot) = v; }
+DEV double ws_load(const Workspace &ws, int slot) { return *ws_at(ws, slot); }
+DEV void ws_store3(const Workspace &ws, int slot, V3 v) { ws_store(ws, slot, v.x); ws_store(ws, slot + 1, v.y); ws_store(ws, slot + 2, v.z); }
+DEV V3 ws_load3(const Workspace &ws, int slot) { return mk(ws_load(ws, slot), ws_load(ws, slot + 1), ws_load(ws, slot + 2)); }
 DEV int fslot(int level, int s) { return LANE_SLOTS + level * FRAME_SLOTS + s; }
 
 // ---- LDS context slots (12 doubles per lane) ----
@@ -622,10 +634,10 @@ constexpr bool kViewInLds = CTX_SLOTS >= 18;  // (development option; the light 
 DEV void cx_store3(lds_dptr cx, int slot, V3 v) { cx[slot * TRACE_BLOCK] = v.x; cx[(slot + 1) * TRACE_BLOCK] = v.y; cx[(slot + 2) * TRACE_BLOCK] = v.z; }
 DEV V3 cx_load3(lds_dptr cx, int slot) { return mk(cx[slot * TRACE_BLOCK], cx[(slot + 1) * TRACE_BLOCK], cx[(slot + 2) * TRACE_BLOCK]); }
 
-#define PARK_V(v) do { if (kViewInLds) cx_store3(cx, CX_V, v); else ws_store3(ws, stride, LS_V, v); } while (0)
-#define LOAD_V() (kViewInLds ? cx_load3(cx, CX_V) : ws_load3(ws, stride, LS_V))
-#define PARK_TERM(v) do { if (term_in_lds) cx_store3(cx, CX_TERM, v); else ws_store3(ws, stride, LS_TERM, v); } while (0)
-#define LOAD_TERM() (term_in_lds ? cx_load3(cx, CX_TERM) : ws_load3(ws, stride, LS_TERM))
+#define PARK_V(v) do { if (kViewInLds) cx_store3(cx, CX_V, v); else ws_store3(ws, LS_V, v); } while (0)
+#define LOAD_V() (kViewInLds ? cx_load3(cx, CX_V) : ws_load3(ws, LS_V))
+#define PARK_TERM(v) do { if (term_in_lds) cx_store3(cx, CX_TERM, v); else ws_store3(ws, LS_TERM, v); } while (0)
+#define LOAD_TERM() (term_in_lds ? cx_load3(cx, CX_TERM) : ws_load3(ws, LS_TERM))
 
 template <bool EXH, bool COUNT, typename StackT>
 static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DParams &prm, void *out,
@@ -641,8 +653,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     stack_ptr stk = (stack_ptr)((lds_dptr)lds + prm.ctx_slots * TRACE_BLOCK) + tid;      // stack column
     const bool term_in_lds = prm.ctx_slots >= 15;  // wave-uniform: the launcher grants 3 more slots when LDS has room
     Tracer<EXH, COUNT, StackT> tr(sc, stk, cnt);
-    double *ws = frames + gtid;
-    const int stride = prm.frame_stride;
+    const Workspace ws = {frames, (unsigned)prm.frame_stride, (unsigned)gtid};
     const uint64_t seed_mixed = mix64(prm.seed + 0x9e3779b97f4a7c15ULL);
 
     // per-lane state that stays in registers across a scene query
@@ -659,8 +670,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     // slot & 63 = Morton position in the tile), item % spp the sample.  A wave draws chunks of kChunk items from
     // the global ticket into a wave-local pool and hands them to its idle lanes, so a lane that finishes a
     // sample gets the next one at once.  (Per-pixel items left the frame waiting on single lanes that
-    // held an expensive pixel: 16 samples in sequence.)  With spp > 1 every sample's radiance goes to a
-    // sample buffer and rayhs_resolve adds them up in sample order, as the reference's fold does.
+    // held an expensive pixel: 16 samples in sequence.)
     constexpr unsigned kChunk = RAYHS_CHUNK;
     const unsigned long long total_items = (unsigned long long)prm.n_tiles * 64ull * (unsigned long long)prm.spp;
     unsigned long long pool_next = 0, pool_end = 0;
@@ -772,7 +782,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                 // traceRay (src/RayHs.hs:149-154)
                 if (tr.bobj < 0) { result = mk(0, 0, 0); step = A_RETURN; }
                 else {
-                    const auto &ob = as_const(sc.objects)[tr.bobj];
+                    const auto &ob = rec(sc.objects, tr.bobj);
                     if (COUNT) cnt.c[CNT_SHADED]++;
                     c_obj = tr.bobj;
                     PARK_V(ray.d);
@@ -781,7 +791,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                     const int mat_kind = ob.mat_kind;
                     const bool need_uv = ((mat_kind == 1 || mat_kind == 2) && ob.cmap_kind != 0) || mat_kind == 6;
                     if (tr.btri >= 0) {
-                        const DTriAttr &at = (tr.bref ? sc.attrs : sc.fattrs)[tr.btri];
+                        const DTriAttr &at = rec(tr.bref ? sc.attrs : sc.fattrs, tr.btri);
                         double u = tr.bu, v = tr.bv, w = 1 - u - v;
                         // barycentricInterp u n1 v n2 (1-u-v) n0 (src/Mesh.hs:53-57,73-74)
                         c_n = add(add(scl(u, ld3(at.n1)), scl(v, ld3(at.n2))), scl(w, ld3(at.n0)));
@@ -790,11 +800,11 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                             hv = u * at.uv1[1] + v * at.uv2[1] + w * at.uv0[1];
                         }
                     } else if (tr.bprim >= 0) {  // re-derive the analytic hit from t
-                        const auto &pl = as_const(sc.planes)[tr.bprim];
+                        const auto &pl = rec(sc.planes, tr.bprim);
                         c_n = ld3(pl.n);
                         if (need_uv) { V3 rel = sub(c_p, ld3(pl.p)); hu = dot(ld3(pl.t), rel); hv = dot(ld3(pl.b), rel); }
                     } else {
-                        const auto &s = as_const(sc.spheres)[-tr.bprim - 2];
+                        const auto &s = rec(sc.spheres, -tr.bprim - 2);
                         c_n = unit(sub(c_p, ld3(s.c)));
                         if (need_uv) polar_uv(c_n, hu, hv);  // src/Geometry.hs:96
                     }
@@ -827,30 +837,30 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
             } else if (state == ST_EXIT) {
                 // the transmitted ray's exit point (src/RayHs.hs:140-143)
                 c_p = cx_load3(cx, CX_P); c_n = cx_load3(cx, CX_N); c_cd = cx_load3(cx, CX_CD);
-                const auto &ob = as_const(sc.objects)[c_obj];
+                const auto &ob = rec(sc.objects, c_obj);
                 bool have = false;
                 if (tr.bobj >= 0) {
                     V3 outp = add(ray.o, scl(tr.bt, ray.d));
                     V3 outn;
                     if (tr.btri >= 0) {
-                        const DTriAttr &at = (tr.bref ? sc.attrs : sc.fattrs)[tr.btri];
+                        const DTriAttr &at = rec(tr.bref ? sc.attrs : sc.fattrs, tr.btri);
                         double u = tr.bu, v = tr.bv, w = 1 - u - v;
                         outn = add(add(scl(u, ld3(at.n1)), scl(v, ld3(at.n2))), scl(w, ld3(at.n0)));
-                    } else if (tr.bprim >= 0) outn = ld3(as_const(sc.planes)[tr.bprim].n);
-                    else outn = unit(sub(outp, ld3(as_const(sc.spheres)[-tr.bprim - 2].c)));
+                    } else if (tr.bprim >= 0) outn = ld3(rec(sc.planes, tr.bprim).n);
+                    else outn = unit(sub(outp, ld3(rec(sc.spheres, -tr.bprim - 2).c)));
                     V3 outdir;
                     if (refract(c_cd, neg(outn), ob.ior, 1.0, outdir)) {
                         have = true;
                         // suspend this irradiance call: radiance child first, specular child later
                         V3 c_v = LOAD_V();
                         V3 rf = reflect(c_v, c_n);
-                        ws_store(ws, stride, fslot(fsp, FS_KIND), (double)FR_TRANS_WAIT_RADIANCE);
-                        ws_store(ws, stride, fslot(fsp, FS_DEPTH), (double)depth);
-                        ws_store(ws, stride, fslot(fsp, FS_F), fresnel(ob.fr, dot(c_n, neg(c_v))));
-                        ws_store(ws, stride, fslot(fsp, FS_S), dot(rf, c_n));
-                        ws_store(ws, stride, fslot(fsp, FS_K), ob.one_m_r0);
-                        ws_store3(ws, stride, fslot(fsp, FS_RO), add(c_p, scl(kEps, rf)));
-                        ws_store3(ws, stride, fslot(fsp, FS_RD), rf);
+                        ws_store(ws, fslot(fsp, FS_KIND), (double)FR_TRANS_WAIT_RADIANCE);
+                        ws_store(ws, fslot(fsp, FS_DEPTH), (double)depth);
+                        ws_store(ws, fslot(fsp, FS_F), fresnel(ob.fr, dot(c_n, neg(c_v))));
+                        ws_store(ws, fslot(fsp, FS_S), dot(rf, c_n));
+                        ws_store(ws, fslot(fsp, FS_K), ob.one_m_r0);
+                        ws_store3(ws, fslot(fsp, FS_RO), add(c_p, scl(kEps, rf)));
+                        ws_store3(ws, fslot(fsp, FS_RD), rf);
                         fsp++;
                         ray.o = add(outp, scl(kEps, outdir)); ray.d = outdir;
                         depth = depth + 1;
@@ -865,7 +875,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
             if (step == A_LIGHT_NEXT) {
                 if (c_li < sc.n_lights) {
                     // lightAt (src/Light.hs:12-17) + diffuse (src/Material.hs:31-33)
-                    const auto &L = as_const(sc.lights)[c_li];
+                    const auto &L = rec(sc.lights, c_li);
                     V3 ld, lc;
                     if (L.kind == 0) { ld = ld3(L.v); lc = ld3(L.c); q_point = false; q_d2 = 0; q_dist = __builtin_inf(); }
                     else {
@@ -885,7 +895,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                     // park the context of the hit being shaded while its shadow ray is traced
                     cx_store3(cx, CX_P, c_p); cx_store3(cx, CX_N, c_n); cx_store3(cx, CX_CD, c_cd); cx_store3(cx, CX_A, c_A);
                     qkind = Q_SHADOW; state = ST_SHADOW; step = A_QUERY_READY;
-                } else if (as_const(sc.objects)[c_obj].mat_kind == 1) {
+                } else if (rec(sc.objects, c_obj).mat_kind == 1) {
                     result = add(scl(0.2, c_cd), c_A);  // Diffuse (src/RayHs.hs:111-114)
                     step = A_RETURN;
                 } else { spec_with_A = true; step = A_SPEC; }  // Plastic (src/RayHs.hs:117-120)
@@ -897,16 +907,16 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
             TIME_ADD(2);  // light section
             if (step == A_SPEC) {
                 // fresnel * specular (src/RayHs.hs:99-104,119,124,132)
-                const auto &ob = as_const(sc.objects)[c_obj];
+                const auto &ob = rec(sc.objects, c_obj);
                 V3 c_v = LOAD_V();
                 double F = fresnel(ob.fr, dot(c_n, neg(c_v)));
                 if (depth < prm.max_depth) {
                     V3 rf = reflect(c_v, c_n);
-                    ws_store(ws, stride, fslot(fsp, FS_KIND), (double)(spec_with_A ? FR_PLASTIC : FR_MIRROR));
-                    ws_store(ws, stride, fslot(fsp, FS_DEPTH), (double)depth);
-                    ws_store(ws, stride, fslot(fsp, FS_F), F);
-                    ws_store(ws, stride, fslot(fsp, FS_S), dot(rf, c_n));
-                    if (spec_with_A) ws_store3(ws, stride, fslot(fsp, FS_A), c_A);
+                    ws_store(ws, fslot(fsp, FS_KIND), (double)(spec_with_A ? FR_PLASTIC : FR_MIRROR));
+                    ws_store(ws, fslot(fsp, FS_DEPTH), (double)depth);
+                    ws_store(ws, fslot(fsp, FS_F), F);
+                    ws_store(ws, fslot(fsp, FS_S), dot(rf, c_n));
+                    if (spec_with_A) ws_store3(ws, fslot(fsp, FS_A), c_A);
                     fsp++;
                     ray.o = add(c_p, scl(kEps, rf)); ray.d = rf;
                     depth = depth + 1;
@@ -938,25 +948,25 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                     step = A_NONE;
                 } else {
                     int lv = fsp - 1;
-                    int kind = (int)ws_load(ws, stride, fslot(lv, FS_KIND));
-                    double F = ws_load(ws, stride, fslot(lv, FS_F)), S = ws_load(ws, stride, fslot(lv, FS_S));
+                    int kind = (int)ws_load(ws, fslot(lv, FS_KIND));
+                    double F = ws_load(ws, fslot(lv, FS_F)), S = ws_load(ws, fslot(lv, FS_S));
                     if (kind == FR_PLASTIC) {
-                        result = add(ws_load3(ws, stride, fslot(lv, FS_A)), scl(F, scl(S, result)));
+                        result = add(ws_load3(ws, fslot(lv, FS_A)), scl(F, scl(S, result)));
                         fsp = lv;
                     } else if (kind == FR_MIRROR) {
                         result = scl(F, scl(S, result));
                         fsp = lv;
                     } else if (kind == FR_TRANS_WAIT_RADIANCE) {
-                        ws_store3(ws, stride, fslot(lv, FS_A), result);
-                        ws_store(ws, stride, fslot(lv, FS_KIND), (double)FR_TRANS_WAIT_SPEC);
-                        ray.o = ws_load3(ws, stride, fslot(lv, FS_RO));
-                        ray.d = ws_load3(ws, stride, fslot(lv, FS_RD));
-                        depth = (int)ws_load(ws, stride, fslot(lv, FS_DEPTH)) + 1;
+                        ws_store3(ws, fslot(lv, FS_A), result);
+                        ws_store(ws, fslot(lv, FS_KIND), (double)FR_TRANS_WAIT_SPEC);
+                        ray.o = ws_load3(ws, fslot(lv, FS_RO));
+                        ray.d = ws_load3(ws, fslot(lv, FS_RD));
+                        depth = (int)ws_load(ws, fslot(lv, FS_DEPTH)) + 1;
                         if (COUNT) cnt.c[CNT_REFLECT]++;
                         qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
                     } else {
-                        double K = ws_load(ws, stride, fslot(lv, FS_K));
-                        result = add(scl(K, ws_load3(ws, stride, fslot(lv, FS_A))), scl(F, scl(S, result)));
+                        double K = ws_load(ws, fslot(lv, FS_K));
+                        result = add(scl(K, ws_load3(ws, fslot(lv, FS_A))), scl(F, scl(S, result)));
                         fsp = lv;
                     }
                 }
