@@ -305,17 +305,25 @@ struct Tracer {
     }
 
     // ---- analytic primitives (src/Geometry.hs:68-96) ----
-    template <class PL> __device__ __forceinline__ bool plane_t(const PL &pl, const Ray &r, double &t) {
-        double dDotn = dot(r.d, ld3(pl.n));
-        double time = dot(ld3(pl.n), sub(ld3(pl.p), r.o)) / dDotn;
-        t = time;
-        return fabs(dDotn) > 0 && time > 0;
+    // Plane (src/Geometry.hs:68-76): time = (n . (p - o)) / (d . n), a hit iff |d . n| > 0 and time > 0.  The two
+    // dot products come first: a quotient of operands with opposite signs (or a zero / NaN operand) can never be
+    // > 0, whatever the rounding, so when no lane of the wave can hit the division is skipped for the whole wave.
+    template <class PL> __device__ __forceinline__ void plane_terms(const PL &pl, const Ray &r, double &num, double &den) {
+        den = dot(r.d, ld3(pl.n));
+        num = dot(ld3(pl.n), sub(ld3(pl.p), r.o));
     }
-    template <class SP> __device__ __forceinline__ bool sphere_t(const SP &s, const Ray &r, double a, double &t) {
+    static __device__ __forceinline__ bool quotient_may_be_positive(double num, double den) {
+        return (num > 0 && den > 0) || (num < 0 && den < 0);
+    }
+    // Sphere (src/Geometry.hs:78-85): the discriminant first; the roots (a square root and two divisions) only when
+    // some lane of the wave has delta >= 0.
+    template <class SP> __device__ __forceinline__ void sphere_terms(const SP &s, const Ray &r, double a, double &b, double &delta) {
         V3 oc = sub(r.o, ld3(s.c));
-        double b = 2.0 * dot(r.d, oc);
+        b = 2.0 * dot(r.d, oc);
         double c = dot(oc, oc) - s.r2;
-        double delta = b * b - 4.0 * a * c;
+        delta = b * b - 4.0 * a * c;
+    }
+    static __device__ __forceinline__ bool sphere_roots(double a, double b, double delta, double &t) {
         // guards of src/Geometry.hs:81-85 in order: delta < 0 -> miss; t0 > 0 -> t0; t1 > 0 -> t1; else miss.
         // Both roots are formed without branching (a NaN from sqrt of a negative delta is masked by the guard).
         double sq = sqrt(delta);
@@ -414,14 +422,28 @@ struct Tracer {
         // ifs cost more scalar exec-mask bookkeeping here than the arithmetic they guard.
         const unsigned long long wave_active = __ballot(active);
         const unsigned long long wave_shadow = __ballot(active && shadow);
+        const double a = dot(r.d, r.d);
+        const double o_max = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z));
+        const double o_guard = (o_max * o_max) * 1e-18;
         for (int i = 0; i < sc.n_planes && wave_active != 0ull; i++) {
             const auto &pl = as_const(sc.planes)[i];
             // outside the exhaustive kernels a shadow query skips Emmit objects and stops at its first occluder
             const bool consider = active && (EXH || !(shadow && (occluded || !pl.occluder)));
             if (__ballot(consider) == 0ull) continue;
             if (COUNT && consider) cnt.c[CNT_PRIMS]++;
-            double t;
-            const bool hit = plane_t(pl, r, t) && consider;
+            double num, den;
+            plane_terms(pl, r, num, den);
+            // a shadow query only asks whether the hit lies in front of the light: with an approximate quotient
+            // (v_rcp_f64, ~1e-8) a plane whose squared hit distance exceeds the light's by more than 1e-4 of it is
+            // settled without the division.  (in_front forms |o - (o + t d)|^2; its cancellation error stays
+            // below that margin unless the origin is 1e9 hit distances away from zero -- then we divide.)
+            const double q = num * __builtin_amdgcn_rcp(den);
+            const double s_far = (q * q) * a;
+            const bool beyond_light = shadow && point_light && s_far * (1.0 - 1e-4) > light_d2 && s_far > o_guard;
+            const bool wanted = consider && quotient_may_be_positive(num, den) && !beyond_light;
+            if (__ballot(wanted) == 0ull) continue;
+            const double t = num / den;
+            const bool hit = consider && fabs(den) > 0 && t > 0;
             if (wave_shadow != 0ull && __ballot(hit && shadow) != 0ull) {
                 const bool front = in_front(r, t, point_light, light_d2);
                 occluded = occluded || (hit && shadow && pl.occluder != 0 && front);
@@ -429,14 +451,15 @@ struct Tracer {
             const bool better = hit && !shadow && (t < bt || (t == bt && pl.obj < bobj));
             bt = better ? t : bt; bobj = better ? pl.obj : bobj; bprim = better ? i : bprim;
         }
-        const double a = dot(r.d, r.d);
         for (int i = 0; i < sc.n_spheres && wave_active != 0ull; i++) {
             const auto &s = as_const(sc.spheres)[i];
             const bool consider = active && (EXH || !(shadow && (occluded || !s.occluder)));
             if (__ballot(consider) == 0ull) continue;
             if (COUNT && consider) cnt.c[CNT_PRIMS]++;
-            double t = 0;
-            const bool hit = consider && sphere_t(s, r, a, t);
+            double b, delta, t = 0;
+            sphere_terms(s, r, a, b, delta);
+            if (__ballot(consider && !(delta < 0.0)) == 0ull) continue;
+            const bool hit = sphere_roots(a, b, delta, t) && consider;
             if (wave_shadow != 0ull && __ballot(hit && shadow) != 0ull) {
                 const bool front = in_front(r, t, point_light, light_d2);
                 occluded = occluded || (hit && shadow && s.occluder != 0 && front);

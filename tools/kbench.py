@@ -38,5 +38,6 @@ for i in range(reps):
     ms.append(s2["kernel_ms"])
 best = min(ms)
 alg = 32 * st["nodes_tested"] + 36 * st["tris_tested"] + 40 * st["prims_tested"] + 60 * st["shaded_hits"] + 12 * st["pixels"]
-print(f"{os.environ.get('RAYHS_LIB','default')} {name}: parity={'OK' if ok else 'FAIL'} kernel_ms={['%.2f'%m for m in ms]} best={best:.2f} "
+med = sorted(ms)[len(ms) // 2]
+print(f"{os.environ.get('RAYHS_LIB','default')} {name}: parity={'OK' if ok else 'FAIL'} kernel_ms: n={len(ms)} median={med:.3f} best={best:.3f} "
       f"Mrays/s={rays/best/1e3:.0f} alg_GB/s={alg/best/1e6:.0f} frac={alg/best/1e6/8000:.3f} nodes={st['nodes_tested']} tris={st['tris_tested']}")
