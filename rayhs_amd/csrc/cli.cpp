@@ -9,7 +9,9 @@
 //   --spp=N --seed=S   multi-sample path (distributedTracePixel semantics)
 //   --device=N         HIP device (default 0)
 //   --stats            work counters and kernel time on stderr
+//   --timing           wall time of each stage (load, upload, render, write) on stderr
 // The trace runs on the GPU through the C ABI; there is no CPU path.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -33,7 +35,7 @@ int main(int argc, char **argv) {
     bool have_output_flag = false;
     int spp = 1, device = 0;
     unsigned long long seed = 24;  // src/RayHs.hs:239
-    bool want_stats = false;
+    bool want_stats = false, want_timing = false;
     std::vector<std::string> errors;
     int i = 1;
     for (; i < argc; i++) {  // RequireOrder: options stop at the first non-option
@@ -60,6 +62,7 @@ int main(int argc, char **argv) {
         else if (long_opt("seed")) { seed = has_val ? std::strtoull(val.c_str(), nullptr, 10) : 24; }
         else if (long_opt("device")) { device = has_val ? std::atoi(val.c_str()) : 0; }
         else if (long_opt("stats")) { want_stats = true; }
+        else if (long_opt("timing")) { want_timing = true; }
         else errors.push_back("unrecognized option `" + a + "'\n");
     }
     if (!errors.empty()) {
@@ -70,6 +73,10 @@ int main(int argc, char **argv) {
     if (i >= argc) die("No input.");
     const std::string scene_file = argv[i];
 
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    const clk::time_point t_start = clk::now();
+    double ms_load = 0, ms_upload = 0, ms_render = 0, ms_write = 0;
     std::printf("Loading scene from %s...\n", scene_file.c_str());
     std::fflush(stdout);
     rayhs_render_desc *rd = nullptr;
@@ -84,8 +91,11 @@ int main(int argc, char **argv) {
     std::fflush(stdout);
     if (rc != RAYHS_OK) die(rayhs_last_error());
 
+    ms_load = ms_since(t_start);
+    clk::time_point t0 = clk::now();
     rayhs_scene *scene = nullptr;
     if (rayhs_scene_create(rayhs_render_desc_scene(rd), device, &scene) != RAYHS_OK) die(rayhs_last_error());
+    ms_upload = ms_since(t0);
     rayhs_render_params p;
     std::memset(&p, 0, sizeof p);
     p.width = rayhs_render_desc_width(rd);
@@ -110,8 +120,12 @@ int main(int argc, char **argv) {
     } else {
         std::vector<int16_t> q((size_t)p.width * (size_t)p.height * 3);
         rayhs_stats st;
+        t0 = clk::now();
         if (rayhs_render(scene, rayhs_render_desc_camera(rd), &p, q.data(), &st) != RAYHS_OK) die(rayhs_last_error());
+        ms_render = ms_since(t0);
+        t0 = clk::now();
         if (rayhs_write_ppm_i16(out_file.c_str(), p.width, p.height, q.data()) != RAYHS_OK) die(rayhs_last_error());
+        ms_write = ms_since(t0);
         if (want_stats) {
             unsigned long long rays = st.rays_primary + st.rays_reflect + st.rays_refract + st.rays_refract_exit + st.rays_shadow;
             std::fprintf(stderr,
@@ -126,6 +140,9 @@ int main(int argc, char **argv) {
     }
     rayhs_scene_destroy(scene);
     rayhs_render_desc_free(rd);
+    if (want_timing)
+        std::fprintf(stderr, "{\"load_ms\": %.1f, \"scene_create_ms\": %.1f, \"render_ms\": %.1f, \"write_ms\": %.1f, \"total_ms\": %.1f}\n",
+                     ms_load, ms_upload, ms_render, ms_write, ms_since(t_start));
     std::printf("Done! Output written to %s\n", out_file.c_str());
     return 0;
 }

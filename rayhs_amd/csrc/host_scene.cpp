@@ -20,6 +20,7 @@
 #include <fstream>
 #include <limits>
 #include <sstream>
+#include <thread>
 
 namespace rayhs {
 
@@ -534,9 +535,28 @@ int to_int_c(double c) {
 }
 
 // writePPM / formatPixelsPPM (src/Image.hs:60-75): "P3\nW H\n255\n", rows joined by '\n', every pixel
-// "r g b" followed by two spaces, no trailing newline.  A 1080p frame is ~20 MB of ASCII (4K: ~80 MB), so
-// the digits are emitted by hand into one buffer (no printf per pixel) and written with a single fwrite.
+// "r g b" followed by two spaces, no trailing newline.  A 1080p frame is ~20 MB of ASCII (4K: ~80 MB): the
+// digits come from a 256-entry table (toIntC yields 0..255 unless a colour is negative), bands of rows are
+// formatted by a few threads into their own buffers, and the bands are written in order.
 static inline char *put_int(char *p, int v) {
+    static const struct Table {
+        char txt[256][4];
+        unsigned char len[256];
+        Table() {
+            for (int k = 0; k < 256; k++) {
+                int n = 0;
+                if (k >= 100) txt[k][n++] = (char)('0' + k / 100);
+                if (k >= 10) txt[k][n++] = (char)('0' + (k / 10) % 10);
+                txt[k][n++] = (char)('0' + k % 10);
+                len[k] = (unsigned char)n;
+                for (; n < 4; n++) txt[k][n] = ' ';
+            }
+        }
+    } table;
+    if ((unsigned)v < 256u) {
+        std::memcpy(p, table.txt[v], 4);  // the bytes after the digits are overwritten by the caller
+        return p + table.len[v];
+    }
     unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
     if (v < 0) *p++ = '-';
     char tmp[12];
@@ -550,21 +570,35 @@ static void write_ppm_impl(const std::string &path, int w, int h, Get get) {
     FILE *f = std::fopen(path.c_str(), "wb");
     if (!f) throw SceneError(RAYHS_ERR_IO, path + ": openFile: permission denied or missing directory");
     const std::string head = "P3\n" + std::to_string(w) + " " + std::to_string(h) + "\n255\n";
-    std::vector<char> buf(head.size() + (size_t)w * (size_t)h * 23 + (size_t)h + 16);  // <= 3 x "-32768" + separators per pixel
-    char *p = buf.data();
-    std::memcpy(p, head.data(), head.size());
-    p += head.size();
-    for (int y = 0; y < h; y++) {
-        if (y) *p++ = '\n';
-        for (int x = 0; x < w; x++) {
-            size_t i = ((size_t)y * (size_t)w + (size_t)x) * 3;
-            p = put_int(p, get(i)); *p++ = ' ';
-            p = put_int(p, get(i + 1)); *p++ = ' ';
-            p = put_int(p, get(i + 2)); *p++ = ' '; *p++ = ' ';
+    const size_t row_worst = (size_t)w * 23 + 8;  // <= 3 x "-32768" + separators per pixel, + newline and table slack
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int n_bands = std::max(1, std::min(std::min(hw > 0 ? hw : 1, 16), h / 32));
+    std::vector<std::vector<char>> bands((size_t)n_bands);
+    auto format_band = [&](int b) {
+        const int y0 = (int)((long long)h * b / n_bands), y1 = (int)((long long)h * (b + 1) / n_bands);
+        std::vector<char> &buf = bands[(size_t)b];
+        buf.resize((size_t)(y1 - y0) * ((size_t)w * 13 + 1) + row_worst);  // typical size; grown below if a row needs more
+        size_t used = 0;
+        for (int y = y0; y < y1; y++) {
+            if (buf.size() - used < row_worst) buf.resize(buf.size() * 2 + row_worst);
+            char *p = buf.data() + used;
+            if (y) *p++ = '\n';
+            for (int x = 0; x < w; x++) {
+                size_t i = ((size_t)y * (size_t)w + (size_t)x) * 3;
+                p = put_int(p, get(i)); *p++ = ' ';
+                p = put_int(p, get(i + 1)); *p++ = ' ';
+                p = put_int(p, get(i + 2)); *p++ = ' '; *p++ = ' ';
+            }
+            used = (size_t)(p - buf.data());
         }
-    }
-    size_t n = (size_t)(p - buf.data());
-    bool ok = std::fwrite(buf.data(), 1, n, f) == n;
+        buf.resize(used);
+    };
+    std::vector<std::thread> workers;
+    for (int b = 1; b < n_bands; b++) workers.emplace_back(format_band, b);
+    format_band(0);
+    for (std::thread &t : workers) t.join();
+    bool ok = std::fwrite(head.data(), 1, head.size(), f) == head.size();
+    for (const std::vector<char> &buf : bands) ok = ok && (buf.empty() || std::fwrite(buf.data(), 1, buf.size(), f) == buf.size());
     if (std::fclose(f) != 0 || !ok) throw SceneError(RAYHS_ERR_IO, path + ": write failed");
 }
 void write_ppm_i16(const std::string &path, int w, int h, const int16_t *q) {
