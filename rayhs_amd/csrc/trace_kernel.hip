@@ -644,7 +644,11 @@ enum : int { LS_V = 0, LS_TERM = 3 };
 enum : int { FS_KIND = 0, FS_DEPTH = 1, FS_F = 2, FS_S = 3, FS_K = 4, FS_A = 5, FS_RO = 8, FS_RD = 11 };
 // slot-major: slot s of lane g sits at frames[s * stride + g]; addressed as uniform base + 32-bit byte offset
 struct Workspace { double *base; unsigned stride, lane; };
-DEV double *ws_at(const Workspace &ws, int slot) { return (double *)((char *)ws.base + ((__umul24((unsigned)slot, ws.stride) + ws.lane) << 3)); }
+DEV double *ws_at(const Workspace &ws, int slot) {
+    unsigned lane = ws.lane;
+    asm volatile("" : "+v"(lane));  // recompute the offset at every use: hoisted out of the main loop, one VGPR per slot would be spilled to scratch
+    return (double *)((char *)ws.base + ((__umul24((unsigned)slot, ws.stride) + lane) << 3));
+}
 DEV void ws_store(const Workspace &ws, int slot, double v) { *ws_at(ws, slot) = v; }
 DEV double ws_load(const Workspace &ws, int slot) { return *ws_at(ws, slot); }
 DEV void ws_store3(const Workspace &ws, int slot, V3 v) { ws_store(ws, slot, v.x); ws_store(ws, slot + 1, v.y); ws_store(ws, slot + 2, v.z); }
