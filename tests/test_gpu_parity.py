@@ -343,6 +343,26 @@ def test_large_mesh_uses_the_wide_stack_kernel(tmp_path):
     assert np.array_equal(fast, want)
 
 
+def _wall(point, normal, colour):
+    return {"geometry": {"type": "plane", "point": dict(zip("xyz", point)), "normal": dict(zip("xyz", normal)), "tangent": {"x": 0.3, "y": 0.2, "z": 1}},
+            "material": {"type": "diffuse", "cd": {"type": "flat", "color": dict(zip("rgb", colour))}}}
+
+
+@pytest.mark.parametrize("offset", [0.0, 1e-12, -1e-12, 1e-7, -1e-7, 3e-5, -3e-5, 1e-3, -1e-3])
+def test_point_light_on_or_next_to_a_wall(tmp_path, offset):
+    # Shadow queries settle "is the wall hit in front of the light?" from an approximate quotient when the answer is
+    # clear and divide exactly otherwise.  Lights sitting on a wall, an ulp in front of it, or just behind it put every
+    # shadow ray of the frame into the ambiguous band; the image must still be the oracle's, bit for bit.
+    walls = [_wall((0, -1, 0), (0, 1, 0), (1, 1, 1)), _wall((0, 1, 0), (0, -1, 0), (1, 1, 1)), _wall((0, 0, 1.5), (0, 0, -1), (0.9, 0.9, 0.9)),
+             _wall((-1, 0, 0), (1, 0.05, 0.02), (1, 0.2, 0.2)), _wall((1, 0, 0), (-1, 0, 0), (0.2, 1, 0.2))]
+    lights = [{"type": "point", "position": {"x": 0.2, "y": 1.0 + offset, "z": 0.4}, "color": {"r": 20, "g": 20, "b": 20}, "radius": 0.1},
+              {"type": "point", "position": {"x": 1.0 + offset, "y": -0.3, "z": 0.9}, "color": {"r": 5, "g": 9, "b": 20}, "radius": 0.1},
+              {"type": "point", "position": {"x": -0.2, "y": 0.1, "z": 1.5 + offset}, "color": {"r": 20, "g": 9, "b": 5}, "radius": 0.2}]
+    got, want, st, ost = _both(_scene_json(walls + [SPH], lights, w=48, h=32, depth=2), tmp_path)
+    assert np.array_equal(got, want)
+    assert st["rays"] == ost["rays"]
+
+
 # ---------------------------------------------------------------------- fuzz
 def _rand_scene(rng):
     def v(lo, hi): return {k: float(rng.uniform(lo, hi)) for k in "xyz"}
