@@ -166,7 +166,8 @@ int rayhs_abi_version(void);
 /* number of visible HIP devices (0 if none or the runtime is unusable) */
 int rayhs_device_count(void);
 
-/* Copies the description into device `device` (HBM-resident until destroy). */
+/* Copies the description into device `device` (HBM-resident until destroy).  Every entry point that takes a
+ * scene makes that device current on the calling thread (hipSetDevice) and leaves it current. */
 int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayhs_scene **out);
 void rayhs_scene_destroy(rayhs_scene *scene);
 
