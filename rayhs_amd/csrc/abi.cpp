@@ -21,6 +21,8 @@ hipError_t launch_trace_fast(int variant, int grid, size_t lds_bytes, hipStream_
                              const DParams &prm, void *out, unsigned long long *counters, unsigned long long *ticket, double *frames);
 hipError_t launch_resolve_fast(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format);
 hipError_t launch_resolve_exact(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format);
+hipError_t launch_order_tiles_fast(hipStream_t stream, float *cost, int n, int *order);
+hipError_t launch_order_tiles_exact(hipStream_t stream, float *cost, int n, int *order);
 hipError_t launch_trace_exact(int variant, int grid, size_t lds_bytes, hipStream_t stream, const DScene &sc, const DCamera &cam,
                               const DParams &prm, void *out, unsigned long long *counters, unsigned long long *ticket, double *frames);
 int occupancy_trace_fast(int variant, size_t lds_bytes);
@@ -66,6 +68,12 @@ struct rayhs_scene {
     mutable unsigned next_ticket = 0;
     mutable unsigned long long *counters = nullptr;
     mutable int grid_cache[2][4][2] = {{{0}}};  // [exact][variant] -> {lds_bytes, blocks per CU}
+    // feedback scheduling (plan_tile_order): chunk times measured by a frame order the tiles of the next one
+    mutable int32_t *order_dev = nullptr;
+    mutable float *cost_dev = nullptr;
+    mutable size_t order_cap = 0;
+    mutable bool order_valid = false;            // order_dev holds an order for order_key
+    mutable int order_key[10] = {0};             // frame geometry the order and the costs belong to
 };
 
 extern "C" const char *rayhs_last_error(void) { return g_error.c_str(); }
@@ -370,6 +378,8 @@ extern "C" void rayhs_scene_destroy(rayhs_scene *s) {
     (void)hipSetDevice(s->device);
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->frames) (void)hipFree(s->frames);
+    if (s->order_dev) (void)hipFree(s->order_dev);
+    if (s->cost_dev) (void)hipFree(s->cost_dev);
     if (s->sbuf) (void)hipFree(s->sbuf);
     if (s->tickets) (void)hipFree(s->tickets);
     if (s->counters) (void)hipFree(s->counters);
@@ -488,6 +498,37 @@ static int ensure_workspace(const rayhs_scene *s, const DParams &dp) {
     return RAYHS_OK;
 }
 
+// Feedback scheduling of the production kernels (why: rayhs_order_tiles in trace_kernel.hip).  Every frame records how
+// long each of its chunks took (DParams.tile_cost) and, right behind it on the same stream, a one-workgroup kernel
+// turns those times into the tile order of the NEXT frame of the same geometry (size, rows, stripes, spp, depth) --
+// the same view in a progressive render or a benchmark, a neighbouring one in an animation.  The first frame of a
+// geometry runs in scan order.  Nothing is read back to the host.
+static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, int variant, DParams &dp, bool &record) {
+    dp.tile_order = nullptr; dp.tile_cost = nullptr; record = false;
+    if ((variant != 0 && variant != 3) || dp.n_tiles < 512 || std::getenv("RAYHS_SCAN_ORDER")) return RAYHS_OK;
+    const int key[10] = {p->width, p->height, p->row0, p->row1, p->stripe_rows, p->stripe_rank, p->stripe_count, p->spp, p->max_depth, dp.n_tiles};
+    if (std::memcmp(key, s->order_key, sizeof key) != 0) {
+        s->order_valid = false;
+        if ((size_t)dp.n_tiles > s->order_cap) {
+            if (s->order_dev) HIP_TRY(hipFree(s->order_dev));
+            if (s->cost_dev) HIP_TRY(hipFree(s->cost_dev));
+            s->order_dev = nullptr; s->cost_dev = nullptr; s->order_cap = 0;
+            void *q = nullptr;
+            HIP_TRY(hipMalloc(&q, (size_t)dp.n_tiles * sizeof(int32_t)));
+            s->order_dev = (int32_t *)q;
+            HIP_TRY(hipMalloc(&q, (size_t)dp.n_tiles * sizeof(float)));
+            s->cost_dev = (float *)q;
+            s->order_cap = (size_t)dp.n_tiles;
+        }
+        HIP_TRY(hipMemset(s->cost_dev, 0, (size_t)dp.n_tiles * sizeof(float)));  // once per geometry; afterwards the ordering kernel clears it
+        std::memcpy(s->order_key, key, sizeof key);
+    }
+    if (s->order_valid) dp.tile_order = s->order_dev;
+    dp.tile_cost = s->cost_dev;
+    record = true;
+    return RAYHS_OK;
+}
+
 static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_render_params *p, void *d_out, hipStream_t st,
                   uint64_t *d_counters, hipEvent_t e0, hipEvent_t e1) {
     DCamera dc; DParams dp; int variant, grid; bool exact; size_t lds;
@@ -498,6 +539,8 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
     if (dp.n_tiles == 0) return RAYHS_OK;
     HIP_TRY(hipSetDevice(s->device));
     if ((rc = ensure_workspace(s, dp))) return rc;
+    bool record_costs = false;
+    if ((rc = plan_tile_order(s, p, variant, dp, record_costs))) return rc;
     unsigned long long *ticket = s->tickets + (size_t)(s->next_ticket++ % kTicketRings) * kTicketSlots;
     HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long) * kTicketSlots, st));
     dp.sbuf = dp.spp > 1 && !dp.wave_resolve ? s->sbuf : nullptr;
@@ -506,6 +549,11 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
                          : launch_trace_fast(variant, grid, lds, st, s->d, dc, dp, d_out, (unsigned long long *)d_counters, ticket, s->frames);
     if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "trace kernel launch failed: %s", hipGetErrorString(e));
     if (e1) HIP_TRY(hipEventRecord(e1, st));
+    if (record_costs) {  // this frame's chunk times -> the next frame's tile order
+        e = exact ? launch_order_tiles_exact(st, s->cost_dev, dp.n_tiles, s->order_dev) : launch_order_tiles_fast(st, s->cost_dev, dp.n_tiles, s->order_dev);
+        if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "tile ordering launch failed: %s", hipGetErrorString(e));
+        s->order_valid = true;
+    }
     if (dp.spp > 1 && !dp.wave_resolve) {
         e = exact ? launch_resolve_exact(st, s->sbuf, d_out, dp.n_rows * dp.width, dp.spp, dp.out_format)
                   : launch_resolve_fast(st, s->sbuf, d_out, dp.n_rows * dp.width, dp.spp, dp.out_format);

@@ -124,6 +124,8 @@ struct DParams {
     double *sbuf;                     // spp > 1: per-sample radiance, 3 doubles per (pixel, sample)
     int32_t wave_resolve;             // 1: spp divides 64, samples are folded inside the wave (no sample buffer)
     int32_t pad_;
+    const int32_t *tile_order;        // work order of the 8x8 tiles, slowest first (NULL: scan order); from the previous frame's tile_cost
+    float *tile_cost;                 // per tile: longest time (100 MHz ticks) one of its chunks took in THIS frame (NULL: not recorded)
 };
 
 // counters[] slots

@@ -728,6 +728,8 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     // whole chunk is done the lane holding sample 0 adds them up in sample order (the reference's foldl) and writes
     // the pixel -- no sample buffer, no resolve pass.
     bool chunk_pending = false, item_valid = false;
+    unsigned long long chunk_t0 = 0;  // when the current chunk was obtained, and the tile it belongs to (a chunk never straddles tiles)
+    int chunk_tile = 0;
     unsigned long long ticket_ahead = 0;  // lane 0: ticket of `range` requested ahead of need
     if (lane == 0) ticket_ahead = atomicAdd(ticket + range * 8, (unsigned long long)kChunk);
 
@@ -737,13 +739,16 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
 #endif
     while (true) {
         unsigned long long idle = __ballot(state == ST_DONE);
-        if (prm.wave_resolve && chunk_pending && idle == ~0ull) {
-            if (item_valid && sample == 0) {
+        if (chunk_pending && idle == ~0ull) {  // the chunk this wave held is finished
+            if (prm.wave_resolve && item_valid && sample == 0) {
                 V3 sum = mk(0, 0, 0);
                 for (int k = 0; k < prm.spp; k++)  // foldl (+) black, samples in order (src/RayHs.hs:169-171)
                     sum = add(sum, mk(cx[CX_A * TRACE_BLOCK + k], cx[(CX_A + 1) * TRACE_BLOCK + k], cx[(CX_A + 2) * TRACE_BLOCK + k]));
                 store_pixel(out, prm.out_format, (size_t)lrow * (size_t)prm.width + (size_t)px, scl(1.0 / (double)prm.spp, sum));
             }
+            // how long the chunk took, for the next frame's work order (costs are >= 0: their bit patterns order like the values)
+            if (prm.tile_cost != nullptr && lane == 0)
+                atomicMax((unsigned *)(prm.tile_cost + chunk_tile), __float_as_uint((float)(__builtin_amdgcn_s_memrealtime() - chunk_t0)));
             chunk_pending = false;
             item_valid = false;
         }
@@ -769,6 +774,11 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                 }
                 if (exhausted) break;
                 if (lane == 0) ticket_ahead = atomicAdd(ticket + range * 8, (unsigned long long)kChunk);
+                if (prm.tile_cost != nullptr) {
+                    const unsigned tslot = (unsigned)(pool_next / ((unsigned long long)prm.spp * 64ull));
+                    chunk_tile = prm.tile_order ? as_const(prm.tile_order)[tslot] : (int)tslot;
+                    chunk_t0 = __builtin_amdgcn_s_memrealtime();
+                }
 #ifdef RAYHS_PROFILE_TIME
                 cnt.c[7]++;  // chunks this wave obtained (lane-0 value is reduced)
                 if (cnt.c[6] == 0) cnt.c[6] = 1;  // waves that obtained any work
@@ -781,7 +791,9 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                 const unsigned long long item = pool_next + rank;
                 const unsigned slot = (unsigned)(item / (unsigned)prm.spp);
                 sample = (int)(item - (unsigned long long)slot * (unsigned)prm.spp);
-                const int tile = (int)(slot >> 6), within = (int)(slot & 63u);
+                // tiles are worked in the order the previous frame measured, slowest first (see rayhs_order_tiles)
+                const int tile = prm.tile_order ? prm.tile_order[slot >> 6] : (int)(slot >> 6);
+                const int within = (int)(slot & 63u);
                 const int ty = tile / prm.tiles_x, tx = tile - ty * prm.tiles_x;
                 // Morton order inside the tile: consecutive slots form 2x2, 4x4, ... blocks, so the few pixels a
                 // wave holds at once are neighbours in both directions
@@ -1082,6 +1094,53 @@ RAYHS_CAT(rayhs_resolve, RAYHS_KERNEL_SUFFIX)(const double *sbuf, void *out, int
     store_pixel(out, out_format, (size_t)i, scl(1.0 / (double)spp, sum));
 }
 
+// Work order of the tiles for the NEXT frame from the chunk times the trace kernel just measured (and clears them).
+// A persistent kernel ends when its slowest wave does.  A chunk of mesh or reflection pixels takes ~1 ms against
+// 0.07 ms for an average one; in scan order such chunks are still being started when the frame is nearly done, and
+// the other waves idled 12 % of the dragon frame waiting for them.  Handing the tiles out by decreasing cost --
+// longest processing time first, with the cost MEASURED on the previous frame (same view, or a neighbouring one in an
+// animation) -- leaves only cheap chunks for the end.  One workgroup: counting sort into 1024 cost classes (the
+// order inside a class does not matter), then the sorted list is dealt in groups of 8 to the 8 bands of the item
+// space (one per XCD, see trace_body), so that every band starts with its share of the slow tiles.
+// Only the order in which pixels are worked on changes, never a result.
+extern "C" __global__ void __launch_bounds__(1024)
+RAYHS_CAT(rayhs_order_tiles, RAYHS_KERNEL_SUFFIX)(float *cost, int n, int *order) {
+    __shared__ unsigned cls_count[1024], cls_start[1024], max_bits;
+    const int t = threadIdx.x;
+    cls_count[t] = 0;
+    if (t == 0) max_bits = 0;
+    __syncthreads();
+    float m = 0.0f;
+    for (int i = t; i < n; i += 1024) m = fmaxf(m, cost[i]);
+    atomicMax(&max_bits, __float_as_uint(m));
+    __syncthreads();
+    const float scale = 1023.0f / fmaxf(__uint_as_float(max_bits), 1.0f);
+    for (int i = t; i < n; i += 1024) atomicAdd(&cls_count[1023 - min(1023, (int)(cost[i] * scale))], 1u);  // class 0 = slowest
+    __syncthreads();
+    // exclusive prefix sum over the 1024 classes (Hillis-Steele)
+    const unsigned v = cls_count[t];
+    cls_start[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned add_ = t >= off ? cls_start[t - off] : 0u;
+        __syncthreads();
+        cls_start[t] += add_;
+        __syncthreads();
+    }
+    cls_start[t] -= v;
+    __syncthreads();
+    const int cycles = n / 64, rest = n % 64;  // sorted position p goes to band (p / 8) % 8
+    for (int i = t; i < n; i += 1024) {
+        const int c = 1023 - min(1023, (int)(cost[i] * scale));
+        const int p = (int)atomicAdd(&cls_start[c], 1u);
+        const int g = p >> 3, band = g & 7;
+        int band_begin = 0;
+        for (int b = 0; b < band; b++) band_begin += cycles * 8 + min(max(rest - 8 * b, 0), 8);
+        order[band_begin + (g >> 3) * 8 + (p & 7)] = i;
+        cost[i] = 0.0f;
+    }
+}
+
 RAYHS_DEFINE_KERNEL(rayhs_trace, false, false, unsigned short, RAYHS_WAVES_PER_EU)       // < 65536 BVH nodes
 RAYHS_DEFINE_KERNEL(rayhs_trace_wide, false, false, unsigned int, RAYHS_WAVES_PER_EU)   // any scene
 #ifdef RAYHS_PROFILE_TIME
@@ -1109,6 +1168,10 @@ hipError_t RAYHS_CAT(launch_trace, RAYHS_KERNEL_SUFFIX)(int variant, int grid, s
 }
 hipError_t RAYHS_CAT(launch_resolve, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format) {
     hipLaunchKernelGGL(RAYHS_CAT(rayhs_resolve, RAYHS_KERNEL_SUFFIX), dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream, sbuf, out, n_pixels, spp, out_format);
+    return hipGetLastError();
+}
+hipError_t RAYHS_CAT(launch_order_tiles, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, float *cost, int n, int *order) {
+    hipLaunchKernelGGL(RAYHS_CAT(rayhs_order_tiles, RAYHS_KERNEL_SUFFIX), dim3(1), dim3(1024), 0, stream, cost, n, order);
     return hipGetLastError();
 }
 int RAYHS_CAT(occupancy_trace, RAYHS_KERNEL_SUFFIX)(int variant, size_t lds_bytes) {
