@@ -216,7 +216,8 @@ def main():
             "data": "synthetic (the reference's own Cornell-box/dragon sample scene; no dataset)",
             "config": {"workload": desc, "scene": scene, "width": w, "height": h, "spp": spp, "max_depth": r.max_depth,
                        "sharding": f"{STRIPE_ROWS}-row stripes interleaved over {world} rank(s), one gather to rank 0",
-                       "kernels": "fma" if args.fma else "exact (-ffp-contract=off, bit-identical to the CPU oracle)"},
+                       "kernels": "fma" if args.fma else "exact (-ffp-contract=off, bit-identical to the CPU oracle)",
+                       "scheduling": "tiles handed out slowest-first, from the chunk times the previous frame measured (ordering kernel inside every step)"},
             "mpixels_per_s": w * h * args.steps / dt / 1e6,
             "rays_per_frame": rays_frame, "kernel_ms_rank0": kernel_ms, "verified_against_single_rank": verified,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -505,7 +505,12 @@ static int ensure_workspace(const rayhs_scene *s, const DParams &dp) {
 // geometry runs in scan order.  Nothing is read back to the host.
 static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, int variant, DParams &dp, bool &record) {
     dp.tile_order = nullptr; dp.tile_cost = nullptr; record = false;
-    if ((variant != 0 && variant != 3) || dp.n_tiles < 512 || std::getenv("RAYHS_SCAN_ORDER")) return RAYHS_OK;
+#ifdef RAYHS_PROFILE_TIME
+    const bool production = variant != 2;  // the diagnostic build's "counting" kernel is the production kernel with time stamps
+#else
+    const bool production = variant == 0 || variant == 3;
+#endif
+    if (!production || dp.n_tiles < 512 || std::getenv("RAYHS_SCAN_ORDER")) return RAYHS_OK;
     const int key[10] = {p->width, p->height, p->row0, p->row1, p->stripe_rows, p->stripe_rank, p->stripe_count, p->spp, p->max_depth, dp.n_tiles};
     if (std::memcmp(key, s->order_key, sizeof key) != 0) {
         s->order_valid = false;
@@ -606,7 +611,7 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
                 stats->nodes_tested = c[CNT_NODES]; stats->tris_tested = c[CNT_TRIS]; stats->prims_tested = c[CNT_PRIMS];
                 stats->shaded_hits = c[CNT_SHADED]; stats->pixels = c[CNT_PIXELS] / (unsigned long long)std::max(p->spp, 1);  // the kernel counts samples
                 if (std::getenv("RAYHS_DEBUG_COUNTERS"))  // development: raw loop counters of a -DRAYHS_PROFILE_LOOPS build
-                    std::fprintf(stderr, "rayhs adv[0..3] %llu %llu %llu %llu span_ticks %llu counters[6..15]: %llu %llu | %llu %llu | %llu %llu %llu %llu %llu %llu  kernel_ms %.3f\n", c[0], c[1], c[2], c[3], c[5] - ~c[4], c[6], c[7], c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], (double)ms);
+                    std::fprintf(stderr, "rayhs adv[0..3] %llu %llu %llu %llu span_ticks %llu latest_end %llu earliest_start %llu counters[6..15]: %llu %llu | %llu %llu | %llu %llu %llu %llu %llu %llu  kernel_ms %.3f\n", c[0], c[1], c[2], c[3], c[5] - ~c[4], c[5], ~c[4], c[6], c[7], c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], (double)ms);
             }
         }
     } while (0);

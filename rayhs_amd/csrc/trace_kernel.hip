@@ -1056,7 +1056,8 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         atomicMax(&counters[4], ~rt0_);
         atomicMax(&counters[5], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
-    cnt.c[9] = __builtin_amdgcn_s_memtime() - mt0_;      // shader-clock ticks over the wave's life
+    cnt.c[9] = __builtin_amdgcn_s_memrealtime();           // summed over waves: (latest end - mean end) is the idle tail
+    (void)mt0_;
 #endif
     if ((COUNT || kProfileTime) && counters != nullptr) {
         for (int i = 0; i < 16; i++) {
