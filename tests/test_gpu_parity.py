@@ -363,6 +363,22 @@ def test_point_light_on_or_next_to_a_wall(tmp_path, offset):
     assert st["rays"] == ost["rays"]
 
 
+def test_feedback_tile_order_never_changes_a_pixel(monkeypatch):
+    # frame 1 runs in scan order and measures chunk times, frames 2 and 3 are worked slowest-tile-first
+    # (rayhs_order_tiles); a frame with the ordering switched off must be the same image, bit for bit
+    r = build_rendering("scenes/dragon_low_1080p.json")
+    frames = [r.ray_trace(spp=4, out_format=L.OUT_F32)[0] for _ in range(3)]
+    assert np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[2])
+    band = [r.ray_trace(spp=4, out_format=L.OUT_F32, row0=400, row1=720, stripe_rows=8, stripe_rank=1, stripe_count=2)[0] for _ in range(2)]
+    assert np.array_equal(band[0], band[1])          # a new geometry starts over in scan order
+    rows = tiles.stripe_rows_of(1, 2, 1080, 8, row0=400, row1=720)
+    assert np.array_equal(band[0], frames[0][rows])
+    monkeypatch.setenv("RAYHS_SCAN_ORDER", "1")
+    plain, _ = r.ray_trace(spp=4, out_format=L.OUT_F32)
+    assert np.array_equal(plain, frames[0])
+    r.close()
+
+
 # ---------------------------------------------------------------------- fuzz
 def _rand_scene(rng):
     def v(lo, hi): return {k: float(rng.uniform(lo, hi)) for k in "xyz"}

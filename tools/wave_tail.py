@@ -22,3 +22,10 @@ for l in out.splitlines():
     if m:
         span, le, es, waves, chunks, life, ends = map(int, m.groups())
         print(f"span {span / 1e5:.3f} ms  waves {waves}  chunks {chunks}  mean life {life / waves / 1e5:.3f} ms  mean idle tail {(le - ends / waves) / 1e5:.3f} ms")
+    m = re.search(r"adv\[0..3\] (\d+) (\d+) (\d+) (\d+) .*counters\[6..15\]: \d+ \d+ \| \d+ \d+ \| (\d+) (\d+) (\d+) (\d+) (\d+) (\d+)", l)
+    if m:
+        v = list(map(int, m.groups()))
+        names = ["refill+loop top", "hit/shadow/exit sections", "light section", "specular section", "return/new sample", "begin (planes, spheres)",
+                 "  slice: mesh start", "  slice: node loop", "  slice: leaves+pop", "slice total"]
+        total = sum(v[:6]) + v[9]
+        print("   " + "; ".join(f"{n} {100 * x / total:.1f}%" for n, x in zip(names, v)))
