@@ -180,8 +180,12 @@ int rayhs_render(const rayhs_scene *scene, const rayhs_camera *camera,
                  const rayhs_render_params *params, void *out_host, rayhs_stats *stats);
 
 /* Renders into a DEVICE buffer on the scene's device, asynchronously on
- * `hip_stream` (a hipStream_t, NULL = default stream).  No host
- * synchronisation, no allocation: safe to enqueue back to back.  If
+ * `hip_stream` (a hipStream_t, NULL = default stream).  Apart from the first
+ * call with a new frame geometry (size, rows, stripes, spp, depth), which
+ * allocates the launch workspace, there is no host synchronisation and no
+ * allocation: safe to enqueue back to back.  Frames of the same geometry
+ * schedule their tiles from the chunk times the previous one measured
+ * (DESIGN.md section 4); results do not depend on it.  If
  * d_counters is non-NULL it must point to 16 zeroed uint64 on the device and
  * RAYHS_FLAG_COUNT must be set. */
 int rayhs_render_device(const rayhs_scene *scene, const rayhs_camera *camera,

@@ -52,8 +52,10 @@ struct alignas(16) DTriAttr {
 };
 
 struct DPlane {   // src/Geometry.hs:62, 70-79
-    double p[3], n[3], t[3], b[3];  // b = cross t n
-    int32_t obj, occluder;          // scene object index; 0 for Emmit (never an occluder, src/RayHs.hs:81)
+    double p[3], n[3];
+    int32_t obj, occluder;          // scene object index; 0 for Emmit (never an occluder, src/RayHs.hs:81).  Next to p and n:
+                                    // the query loop then gets everything it needs from one scalar-load round trip
+    double t[3], b[3];              // b = cross t n (only the UV of a shaded hit reads these)
 };
 struct DSphere {  // src/Geometry.hs:63, 81-96
     double c[3], r2;                // r2 = r ^ 2
