@@ -263,6 +263,8 @@ DEV float f32_up(double v) {  // smallest float >= v (v >= 0 here)
     return f;
 }
 
+constexpr int kTileBits = 28, kTileMask = (1 << kTileBits) - 1;  // tile-order entry: tile index | issue-priority class << 28
+
 // ---- per-lane reads of scene records: uniform base (an SGPR pair) + 32-bit byte offset, so that the load uses the
 // scalar-base addressing form instead of 64-bit per-lane pointer arithmetic (abi.cpp keeps every array < 4 GiB)
 template <typename T> DEV const T &rec(const T *base, int index) {
@@ -776,8 +778,18 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                 if (lane == 0) ticket_ahead = atomicAdd(ticket + range * 8, (unsigned long long)kChunk);
                 if (prm.tile_cost != nullptr) {
                     const unsigned tslot = (unsigned)(pool_next / ((unsigned long long)prm.spp * 64ull));
-                    chunk_tile = prm.tile_order ? as_const(prm.tile_order)[tslot] : (int)tslot;
+                    const int entry = prm.tile_order ? as_const(prm.tile_order)[tslot] : (int)tslot;
+                    chunk_tile = entry & kTileMask;
                     chunk_t0 = __builtin_amdgcn_s_memrealtime();
+                    // the slower the tile was last time, the higher this wave's issue priority while it works on it: a
+                    // chunk is a chain of dependent queries, and when a frame is small (one GPU's share of eight) the
+                    // longest chain, not the total work, decides when the kernel ends (-7 % on a 1/8 share)
+                    switch ((unsigned)entry >> kTileBits) {
+                    case 0: __builtin_amdgcn_s_setprio(0); break;
+                    case 1: __builtin_amdgcn_s_setprio(1); break;
+                    case 2: __builtin_amdgcn_s_setprio(2); break;
+                    default: __builtin_amdgcn_s_setprio(3); break;
+                    }
                 }
 #ifdef RAYHS_PROFILE_TIME
                 cnt.c[7]++;  // chunks this wave obtained (lane-0 value is reduced)
@@ -792,7 +804,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                 const unsigned slot = (unsigned)(item / (unsigned)prm.spp);
                 sample = (int)(item - (unsigned long long)slot * (unsigned)prm.spp);
                 // tiles are worked in the order the previous frame measured, slowest first (see rayhs_order_tiles)
-                const int tile = prm.tile_order ? prm.tile_order[slot >> 6] : (int)(slot >> 6);
+                const int tile = prm.tile_order ? (prm.tile_order[slot >> 6] & kTileMask) : (int)(slot >> 6);
                 const int within = (int)(slot & 63u);
                 const int ty = tile / prm.tiles_x, tx = tile - ty * prm.tiles_x;
                 // Morton order inside the tile: consecutive slots form 2x2, 4x4, ... blocks, so the few pixels a
@@ -1137,7 +1149,9 @@ RAYHS_CAT(rayhs_order_tiles, RAYHS_KERNEL_SUFFIX)(float *cost, int n, int *order
         const int g = p >> 3, band = g & 7;
         int band_begin = 0;
         for (int b = 0; b < band; b++) band_begin += cycles * 8 + min(max(rest - 8 * b, 0), 8);
-        order[band_begin + (g >> 3) * 8 + (p & 7)] = i;
+        // issue priority of the wave that will work on it: 0..3 by quarters of the slowest tile's time
+        const int prio = min(3, (int)(cost[i] * scale * (4.0f / 1024.0f)));
+        order[band_begin + (g >> 3) * 8 + (p & 7)] = i | (prio << kTileBits);
         cost[i] = 0.0f;
     }
 }
