@@ -420,11 +420,12 @@ def _rand_scene(rng):
     cam = {"position": pos, "target": {"x": 0.0, "y": 0.0, "z": 0.0} if axis_aligned else v(-0.3, 0.3), "up": {"x": 0, "y": 1, "z": 0},
            "projection": {"type": str(rng.choice(["perspective", "perspective", "orthographic"])), "fovy": float(rng.uniform(0.5, 1.2)),
                           "width": 2, "height": 2, "near": 0.1}}
-    w, h = (int(rng.integers(3, 9)) * 4, int(rng.integers(3, 9)) * 2)
+    scale = int(os.environ.get("RAYHS_FUZZ_SCALE", "1"))  # soak runs: larger frames reach the tile-ordering path
+    w, h = (int(rng.integers(3, 9)) * 4 * scale, int(rng.integers(3, 9)) * 2 * scale)
     return {"width": w, "height": h, "maxDepth": int(rng.integers(0, 5)), "camera": cam, "scene": {"objects": objs, "lights": lights}}
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RAYHS_FUZZ_SEEDS", "24"))))  # RAYHS_FUZZ_SEEDS=400 for a long soak
 def test_random_scenes_bit_exact(tmp_path, seed):
     rng = np.random.default_rng(1000 + seed)
     jd = _rand_scene(rng)
@@ -436,6 +437,11 @@ def test_random_scenes_bit_exact(tmp_path, seed):
     same = (got == want) | (np.isnan(got) & np.isnan(want))     # NaN colours are legal (e.g. 0/0 in a degenerate scene)
     assert same.all(), (seed, np.abs(np.nan_to_num(got) - np.nan_to_num(want)).max(), int((~same).any(axis=2).sum()))
     assert st["rays"] == ost["rays"], seed
+    r = build_rendering(str(p))                                  # the production kernels: first frame in scan order, second re-ordered
+    for _ in range(2):
+        img, _ = r.ray_trace(spp=spp)
+        assert ((img == want) | (np.isnan(img) & np.isnan(want))).all(), seed
+    r.close()
 
 
 def test_rays_through_mesh_vertices_and_edges(tmp_path):
