@@ -471,6 +471,12 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     }
     int wanted = (dp.n_tiles + 3) / 4;  // 4 waves per workgroup, one tile per wave at a time
     grid = std::max(1, std::min(wanted, s->cu_count * cache[1]));
+    // the continuation workspace (6 + 14 * maxDepth doubles per resident lane) is addressed with 32-bit byte offsets:
+    // a very deep recursion limit runs on a smaller persistent grid rather than failing
+    const size_t lane_bytes = ((size_t)LANE_SLOTS + (size_t)std::max(dp.max_depth, 1) * FRAME_SLOTS) * sizeof(double);
+    const size_t max_blocks = (((size_t)1 << 32) - 1) / (lane_bytes * TRACE_BLOCK);
+    if (max_blocks < 1) return set_error(RAYHS_ERR_UNSUPPORTED, "maxDepth %d needs %zu bytes of continuation frames per lane; the limit is 16 MiB", dp.max_depth, lane_bytes);
+    grid = (int)std::min<size_t>((size_t)grid, max_blocks);
     dp.frame_stride = grid * TRACE_BLOCK;
     return RAYHS_OK;
 }

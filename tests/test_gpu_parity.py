@@ -379,6 +379,21 @@ def test_feedback_tile_order_never_changes_a_pixel(monkeypatch):
     r.close()
 
 
+def test_very_deep_recursion_limit_runs_on_a_smaller_grid(tmp_path):
+    # two facing mirrors: rays bounce until maxDepth; 14 doubles of continuation frame per level and lane make the
+    # workspace outgrow 32-bit offsets unless the persistent grid shrinks (abi.cpp prepare_launch)
+    def mirror(z, nz):
+        return {"geometry": {"type": "plane", "point": {"x": 0, "y": 0, "z": z}, "normal": {"x": 0, "y": 0, "z": nz}, "tangent": {"x": 1, "y": 0, "z": 0}},
+                "material": {"type": "mirror", "ior": 1.8}}
+    ball = {"geometry": {"type": "sphere", "center": {"x": 0.3, "y": -0.2, "z": 0.5}, "radius": 0.25},
+            "material": {"type": "plastic", "ior": 1.5, "cd": {"type": "flat", "color": {"r": 0.9, "g": 0.4, "b": 0.2}}}}
+    text = _scene_json([mirror(2.0, -1), mirror(-3.0, 1), ball], [PT], w=64, h=64, depth=1500)
+    got, want, st, ost = _both(text, tmp_path)
+    assert np.array_equal(got, want) and st["rays"] == ost["rays"]
+    fast, _ = rayhs_amd.ray_trace_file(str(tmp_path / "s.json"))
+    assert np.array_equal(fast, want)
+
+
 # ---------------------------------------------------------------------- fuzz
 def _rand_scene(rng):
     def v(lo, hi): return {k: float(rng.uniform(lo, hi)) for k in "xyz"}
