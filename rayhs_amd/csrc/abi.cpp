@@ -443,8 +443,14 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     dp.out_format = p->out_format;
     // samples of a pixel are folded inside the wave when they all sit in one 64-item chunk (trace_kernel.hip)
     dp.wave_resolve = (p->spp > 1 && 64 % p->spp == 0 && !std::getenv("RAYHS_NO_WAVE_RESOLVE")) ? 1 : 0;
+    auto log2_exact = [](int v) { int s = 0; while ((1 << s) < v) s++; return (1 << s) == v ? s : -1; };
+    dp.spp_shift = log2_exact(p->spp);
+    dp.stripe_shift = log2_exact(p->stripe_rows);
     dp.tiles_x = (p->width + 7) / 8;
+    dp.inv_tiles_x = 1.0f / (float)dp.tiles_x;
     dp.n_tiles = dp.tiles_x * ((rows + 7) / 8);
+    // the refill finds a tile's row and column with a float reciprocal plus one correction step (trace_kernel.hip)
+    if (dp.n_tiles >= (1 << 24) || rows >= (1 << 23)) return set_error(RAYHS_ERR_UNSUPPORTED, "frame too large: %d tiles of 8x8 pixels (limit 2^24)", dp.n_tiles);
     exact = (p->flags & RAYHS_FLAG_FMA) == 0;
     // kernel variants: 0 fast (16-bit stack entries, < 65536 BVH nodes), 3 fast (32-bit entries),
     // 1 counting, 2 exhaustive + counting (the reference's tree)

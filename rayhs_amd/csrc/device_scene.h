@@ -125,7 +125,9 @@ struct DParams {
     int32_t frame_stride;             // threads in the grid (workspace stride)
     double *sbuf;                     // spp > 1: per-sample radiance, 3 doubles per (pixel, sample)
     int32_t wave_resolve;             // 1: spp divides 64, samples are folded inside the wave (no sample buffer)
-    int32_t pad_;
+    int32_t spp_shift;                // log2(spp) when spp is a power of two, else -1 (the refill then divides)
+    int32_t stripe_shift;             // log2(stripe_rows) when that is a power of two, else -1
+    float inv_tiles_x;                // 1 / tiles_x: tile -> (row, column) of the tile grid without an integer division
     const int32_t *tile_order;        // work order of the 8x8 tiles, slowest first (NULL: scan order); from the previous frame's tile_cost
     float *tile_cost;                 // per tile: longest time (100 MHz ticks) one of its chunks took in THIS frame (NULL: not recorded)
 };

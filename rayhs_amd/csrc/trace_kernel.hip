@@ -801,12 +801,15 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
             const bool take = ((idle >> lane) & 1ull) && rank < avail;
             if (take) {
                 const unsigned long long item = pool_next + rank;
-                const unsigned slot = (unsigned)(item / (unsigned)prm.spp);
+                // (the divisions of this block ran 518 k times per frame in every lane: shifts and a corrected float
+                // reciprocal where the operands allow it)
+                const unsigned slot = prm.spp_shift >= 0 ? (unsigned)(item >> prm.spp_shift) : (unsigned)(item / (unsigned)prm.spp);
                 sample = (int)(item - (unsigned long long)slot * (unsigned)prm.spp);
                 // tiles are worked in the order the previous frame measured, slowest first (see rayhs_order_tiles)
                 const int tile = prm.tile_order ? (prm.tile_order[slot >> 6] & kTileMask) : (int)(slot >> 6);
                 const int within = (int)(slot & 63u);
-                const int ty = tile / prm.tiles_x, tx = tile - ty * prm.tiles_x;
+                int ty = (int)((float)tile * prm.inv_tiles_x), tx = tile - ty * prm.tiles_x;  // tile < 2^24: off by one at most
+                if (tx < 0) { ty--; tx += prm.tiles_x; } else if (tx >= prm.tiles_x) { ty++; tx -= prm.tiles_x; }
                 // Morton order inside the tile: consecutive slots form 2x2, 4x4, ... blocks, so the few pixels a
                 // wave holds at once are neighbours in both directions
                 px = tx * 8 + ((within & 1) | ((within >> 1) & 2) | ((within >> 2) & 4));
@@ -814,8 +817,12 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                 item_valid = px < prm.width && lrow < prm.n_rows;
                 if (item_valid) {
                     // local row -> image row (stripe interleave, include/rayhs.h)
-                    int s_local = lrow / prm.stripe_rows, in_stripe = lrow - s_local * prm.stripe_rows;
-                    yrow = prm.row0 + (s_local * prm.stripe_count + prm.stripe_rank) * prm.stripe_rows + in_stripe;
+                    if (prm.stripe_count == 1) yrow = prm.row0 + lrow;
+                    else {
+                        const int s_local = prm.stripe_shift >= 0 ? lrow >> prm.stripe_shift : lrow / prm.stripe_rows;
+                        const int in_stripe = lrow - s_local * prm.stripe_rows;
+                        yrow = prm.row0 + (s_local * prm.stripe_count + prm.stripe_rank) * prm.stripe_rows + in_stripe;
+                    }
                     state = ST_NEW_SAMPLE;
                 }
             }
