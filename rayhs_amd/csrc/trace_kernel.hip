@@ -744,8 +744,13 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         if (chunk_pending && idle == ~0ull) {  // the chunk this wave held is finished
             if (prm.wave_resolve && item_valid && sample == 0) {
                 V3 sum = mk(0, 0, 0);
-                for (int k = 0; k < prm.spp; k++)  // foldl (+) black, samples in order (src/RayHs.hs:169-171)
-                    sum = add(sum, mk(cx[CX_A * TRACE_BLOCK + k], cx[(CX_A + 1) * TRACE_BLOCK + k], cx[(CX_A + 2) * TRACE_BLOCK + k]));
+                auto at = [&](int k) { return mk(cx[CX_A * TRACE_BLOCK + k], cx[(CX_A + 1) * TRACE_BLOCK + k], cx[(CX_A + 2) * TRACE_BLOCK + k]); };
+                int k = 0;
+                for (; k + 4 <= prm.spp; k += 4) {  // foldl (+) black, samples in order (src/RayHs.hs:169-171);
+                    const V3 a = at(k), b = at(k + 1), c = at(k + 2), d = at(k + 3);  // four at a time: one LDS wait, same order of additions
+                    sum = add(add(add(add(sum, a), b), c), d);
+                }
+                for (; k < prm.spp; k++) sum = add(sum, at(k));
                 store_pixel(out, prm.out_format, (size_t)lrow * (size_t)prm.width + (size_t)px, scl(1.0 / (double)prm.spp, sum));
             }
             // how long the chunk took, for the next frame's work order (costs are >= 0: their bit patterns order like the values)
