@@ -18,6 +18,18 @@ for f in glob.glob(f"{src}/{tag}_trace/*/*_kernel_stats.csv"):
     with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as g:
         w = csv.DictWriter(g, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
     out["kernel_stats"] = {r["Name"]: {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6, "pct": float(r["Percentage"])} for r in keep}
+# the same kernel over the TIMED launches only (the --stats average also covers the warm-up frames, the first of
+# which run in scan order): the last `steps` dispatches of the trace kernel in the kernel trace of the bench run
+for f in glob.glob(f"{src}/{tag}_trace/*/*_kernel_trace.csv"):
+    try:
+        steps = json.load(open(f"{src}/{tag}_trace_bench.json"))["steps"]
+    except Exception:
+        steps = 0
+    rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("rayhs_trace") and "count" not in r["Kernel_Name"]]
+    if steps and len(rows) >= steps:
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows[-steps:]]
+        out["timed_launches"] = {"kernel": rows[-1]["Kernel_Name"], "launches": steps, "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d),
+                                 "bench_events_avg_ms": json.load(open(f"{src}/{tag}_trace_bench.json")).get("kernel_ms_rank0")}
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}
 for f in glob.glob(f"{src}/{tag}_pmc_*/*/*_counter_collection.csv"):
