@@ -40,6 +40,7 @@ WORKLOADS = {
     "dragon4k": ("scenes/dragon_4k.json", 64, "dragon.obj in Cornell box 3840x2160, 64 spp, maxDepth 3 (BASELINE configs[4])"),
 }
 STRIPE_ROWS = 8
+IN_FLIGHT = int(os.environ.get("RAYHS_BENCH_IN_FLIGHT", "2"))  # frames enqueued at a time, each on its own scene handle and stream (see main)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -134,13 +135,15 @@ def main():
     # Two frames in flight: each slot has its own scene handle (13 MB of HBM, its own launch workspace and tile order),
     # its own stream and its own gather buffers.  A persistent kernel ends with its slowest wave, so the last part of
     # frame i leaves most of the chip idle; frame i + 1, enqueued on the other stream, starts in those idle CUs, and the
-    # gather of frame i (RCCL's stream) runs beside it.  (tools/overlap_frames.py: 1.39 -> 1.08 ms per frame for a
-    # 1/8 share of the 1080p frame, 7.62 -> 7.58 ms for the whole frame.)
-    renderings = [Rendering(rd, device=local_rank) for _ in range(2)]
+    # gather of frame i (RCCL's stream) runs beside it.  (tools/overlap_frames.py, per frame: a 1/8 share of the 1080p
+    # frame 1.39 ms alone, 1.08 with two in flight; the whole frame 7.62 -> 7.58 ms.  Three in flight: 0.98 ms for the
+    # share in that tool, but in this loop the whole frame gets slower, 7.57 -> 7.8 ms: two trace kernels then run
+    # side by side for most of their time instead of tail to head.)
+    renderings = [Rendering(rd, device=local_rank) for _ in range(IN_FLIGHT)]
     r = renderings[0]
     w, h = r.width, r.height
-    slots = [tiles.FrameGather(rank, world, h, w, STRIPE_ROWS, dev, torch.float32) for _ in range(2)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    slots = [tiles.FrameGather(rank, world, h, w, STRIPE_ROWS, dev, torch.float32) for _ in range(IN_FLIGHT)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(IN_FLIGHT)]
     g = slots[0]
     flags = L.FLAG_FMA if args.fma else 0
     kw = dict(spp=spp, seed=24, stripe_rows=STRIPE_ROWS, stripe_rank=rank, stripe_count=world, out_format=L.OUT_F32)
@@ -149,22 +152,22 @@ def main():
     pending = []
 
     def step(i, ev=None):
-        j = i % 2
+        j = i % IN_FLIGHT
         cur = slots[j]
         with torch.cuda.stream(streams[j]):  # the collective waits for, and the assembly runs on, the slot's stream
             # the library records the two HIP events on the stream right around the trace kernel itself
             renderings[j].ray_trace_device(cur.local.data_ptr(), streams[j].cuda_stream, flags=flags,
                                            events=(ev[0].cuda_event, ev[1].cuda_event) if ev else None, **kw)
             cur.gather_start()
-        if pending:
-            k, prev = pending.pop()
-            with torch.cuda.stream(streams[k]):
-                prev.gather_finish()  # frame i - 1: its transfer ran beside this frame's trace
         pending.append((j, cur))
+        if len(pending) == IN_FLIGHT:  # the oldest frame in flight: its transfer ran beside the traces enqueued since
+            k, prev = pending.pop(0)
+            with torch.cuda.stream(streams[k]):
+                prev.gather_finish()
 
     def drain():
         while pending:
-            k, prev = pending.pop()
+            k, prev = pending.pop(0)
             with torch.cuda.stream(streams[k]):
                 prev.gather_finish()
 
@@ -193,8 +196,8 @@ def main():
     drain()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for i, (a, b) in enumerate(events):  # torch creates the underlying hipEvent lazily, on first record
-        a.record(streams[i % 2])
-        b.record(streams[i % 2])
+        a.record(streams[i % IN_FLIGHT])
+        b.record(streams[i % IN_FLIGHT])
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -209,7 +212,7 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
 
     if rank == 0:
-        frame = slots[(args.steps - 1) % 2].frame
+        frame = slots[(args.steps - 1) % IN_FLIGHT].frame
         assert torch.isfinite(frame).all() and frame.shape == (h, w, 3)
         verified = None
         if args.verify:
@@ -227,7 +230,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (the reference's own Cornell-box/dragon sample scene; no dataset)",
             "config": {"workload": desc, "scene": scene, "width": w, "height": h, "spp": spp, "max_depth": r.max_depth,
-                       "frames_in_flight": 2, "sharding": f"{STRIPE_ROWS}-row stripes interleaved over {world} rank(s), one gather to rank 0",
+                       "frames_in_flight": IN_FLIGHT, "sharding": f"{STRIPE_ROWS}-row stripes interleaved over {world} rank(s), one gather to rank 0",
                        "kernels": "fma" if args.fma else "exact (-ffp-contract=off, bit-identical to the CPU oracle)",
                        "scheduling": "tiles handed out slowest-first, from the chunk times the previous frame measured (ordering kernel inside every step)"},
             "mpixels_per_s": w * h * args.steps / dt / 1e6,
