@@ -272,6 +272,26 @@ def test_full_size_properties(scene, spp):
     r.close()
 
 
+def test_4k_frame_every_tile_lands_where_it_should():
+    # 3840x2160 = 480 x 270 tiles: the refill maps a tile index to its row and column with a float reciprocal and
+    # one correction step, and frames 2.. are worked in measured-cost order; bands of the frame against the oracle
+    # and an 8-rank stripe decomposition against the whole frame
+    scene = "scenes/dragon_4k.json"
+    r = build_rendering(scene)
+    h = r.height
+    frames = [r.ray_trace(spp=1)[0] for _ in range(2)]
+    assert np.array_equal(frames[0], frames[1])
+    for y0 in (0, 1079, 2152):
+        want, _ = oracle_image(scene, spp=1, row0=y0, row1=y0 + 8)
+        assert np.array_equal(frames[1][y0:y0 + 8], want), y0
+    whole = np.empty_like(frames[0])
+    for rank in range(8):
+        part, _ = r.ray_trace(spp=1, stripe_rows=8, stripe_rank=rank, stripe_count=8)
+        whole[tiles.stripe_rows_of(rank, 8, h, 8)] = part
+    assert np.array_equal(whole, frames[0])
+    r.close()
+
+
 def test_headline_scene_band_against_oracle():
     scene = "scenes/dragon_1080p.json"
     r = build_rendering(scene)
