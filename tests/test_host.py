@@ -8,6 +8,7 @@ import ctypes as C
 import json
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -29,6 +30,21 @@ def test_library_is_in_tree_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert L.load().rayhs_abi_version() == 1
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    # the drop-in boundary is a C ABI: include/rayhs.h must compile as strict C99 and link without any C++ or HIP header
+    src = tmp_path / "client.c"
+    src.write_text('#include "rayhs.h"\n#include <stdio.h>\n'
+                   'int main(void) { rayhs_render_params p; rayhs_stats st; (void)p; (void)st;\n'
+                   '  printf("%d %d\\n", rayhs_abi_version(), rayhs_device_count()); return rayhs_last_error() == 0; }\n')
+    exe = tmp_path / "client"
+    bindir = os.path.dirname(L.LIB_PATH)
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                         "-L", bindir, "-lrayhs_hip", "-Wl,-rpath," + bindir], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0 and run.stdout.split()[0] == "1"
 
 
 def test_struct_sizes_match_the_header():
