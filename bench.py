@@ -68,8 +68,18 @@ def measured_traffic(workload):
     return best
 
 
-def cpu_baseline(scene, spp, seconds, threads):
-    """Time the oracle on evenly spread single rows of the same frame for about `seconds`."""
+def golden_digest(workload):
+    """sha256 of the oracle's whole fp32 frame of this workload (tests/golden/frame_digests.json, made once in the
+    build container by tests/golden/make_frame_digests.py), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "frame_digests.json")))[workload]["sha256_f32"]
+    except Exception:
+        return None
+
+
+def cpu_baseline(scene, spp, seconds, threads, frame=None):
+    """Time the oracle on evenly spread single rows of the same frame for about `seconds`.  `frame` (numpy fp32
+    [h, w, 3], the frame the GPU just rendered): the oracle's rows are also compared with it, bit for bit."""
     from oracle import oracle as O
     jd = O.load_render_desc(scene)
     sc = O.Scene(jd["scene"])
@@ -82,12 +92,19 @@ def cpu_baseline(scene, spp, seconds, threads):
     n = int(max(4, min(h, seconds / max(per_row, 1e-6))))
     rows = sorted({int((i + 0.5) * h / n) for i in range(n)})
     rays = 0
+    images = []
     t = time.perf_counter()
     for y in rows:
-        _, st = sc.render(cam, w, h, d, spp=spp, row0=y, row1=y + 1, nthreads=threads)
+        img, st = sc.render(cam, w, h, d, spp=spp, row0=y, row1=y + 1, nthreads=threads)
         rays += st["rays"]
+        images.append(img)
     dt = time.perf_counter() - t
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    checked = None
+    if frame is not None:
+        import numpy as np
+        bad = [y for y, img in zip(rows, images) if not np.array_equal(img[0].astype(np.float32), frame[y])]
+        checked = {"rows": len(rows), "bit_exact": not bad, "first_bad_rows": bad[:8]}
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "gpu_rows_checked": checked,
             "sample": f"{len(rows)} rows spread evenly over the {w}x{h} frame at {spp} spp ({rays} rays in {dt:.1f} s); "
                       "C restatement of the reference algorithm (oracle/), OpenMP over pixels",
             "mpixels_per_s": len(rows) * w / dt / 1e6}
@@ -193,9 +210,17 @@ def main():
 
     # set-up, like the instrumented run above: the first frame a scene handle renders runs in scan order and measures
     # the chunk times that order every later frame; the warm-up and timed steps are steady state
-    for j in range(IN_FLIGHT):
-        renderings[j].ray_trace_device(slots[j].local.data_ptr(), streams[j].cuda_stream, flags=flags, **kw)
+    # The first of them is timed on its own: it is the only frame a one-shot `rayhs -oX scene.json` ever renders
+    # (src/RayHs.hs:215-234) -> first_frame_ms.
+    ff = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    for e in ff:
+        e.record(streams[0])
     torch.cuda.synchronize()
+    for j in range(IN_FLIGHT):
+        renderings[j].ray_trace_device(slots[j].local.data_ptr(), streams[j].cuda_stream, flags=flags,
+                                       events=(ff[0].cuda_event, ff[1].cuda_event) if j == 0 else None, **kw)
+        torch.cuda.synchronize()
+    first_frame_ms = ff[0].elapsed_time(ff[1])
     for i in range(args.warmup):
         step(i)
     drain()
@@ -227,6 +252,14 @@ def main():
             verified = bool(torch.equal(whole, frame))
             if not verified:
                 raise SystemExit("bench.py --verify: the gathered frame differs from the single-rank render")
+        # parity of the frame the timed loop produced: (a) sha256 against the oracle's whole frame (committed digest),
+        # (b) below, the rows the CPU-baseline leg renders anyway, bit for bit.  A mismatch fails the run.
+        host_frame = frame.cpu().numpy() if world >= 1 else None
+        import hashlib
+        want_sha = None if args.fma else golden_digest(args.workload)
+        golden_ok = None if want_sha is None else hashlib.sha256(host_frame.tobytes()).hexdigest() == want_sha
+        if golden_ok is False:
+            raise SystemExit("bench.py: the rendered frame differs from the oracle's frame digest (tests/golden/frame_digests.json)")
         alg = algorithmic_bytes(mine)
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -239,7 +272,9 @@ def main():
                        "kernels": "fma" if args.fma else "exact (-ffp-contract=off, bit-identical to the CPU oracle)",
                        "scheduling": "tiles handed out slowest-first, from the chunk times the previous frame measured (ordering kernel inside every step)"},
             "mpixels_per_s": w * h * args.steps / dt / 1e6,
-            "rays_per_frame": rays_frame, "kernel_ms_rank0": kernel_ms, "verified_against_single_rank": verified,
+            "rays_per_frame": rays_frame, "kernel_ms_rank0": kernel_ms, "first_frame_ms": first_frame_ms,
+            "verified_against_single_rank": verified,
+            "verified_against_oracle": {"whole_frame_sha256_equals_oracle_digest": golden_ok, "rows_against_live_oracle": None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(args.workload) if world == 1 else None,
                          "algorithmic_bytes_per_launch": alg,
@@ -248,7 +283,11 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             threads = max(1, min(16, len(os.sched_getaffinity(0))))
-            out["cpu_baseline"] = cpu_baseline(scene, spp, args.cpu_seconds, threads)
+            out["cpu_baseline"] = cpu_baseline(scene, spp, args.cpu_seconds, threads, None if args.fma else host_frame)
+            chk = out["cpu_baseline"].pop("gpu_rows_checked")
+            out["verified_against_oracle"]["rows_against_live_oracle"] = chk
+            if chk and not chk["bit_exact"]:
+                raise SystemExit(f"bench.py: GPU frame differs from the live oracle on rows {chk['first_bad_rows']}")
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -187,14 +187,25 @@ int rayhs_render(const rayhs_scene *scene, const rayhs_camera *camera,
  * schedule their tiles from the chunk times the previous one measured
  * (DESIGN.md section 4); results do not depend on it.  If
  * d_counters is non-NULL it must point to 16 zeroed uint64 on the device and
- * RAYHS_FLAG_COUNT must be set. */
+ * RAYHS_FLAG_COUNT must be set.
+ *
+ * Streams: a scene handle owns ONE set of launch state (continuation workspace,
+ * sample buffer, tile costs and order), so launches of one handle never run
+ * side by side.  On one stream they are ordered anyway; when a call names a
+ * different stream than the previous call on the same handle (including a
+ * switch between rayhs_render, which uses the NULL stream, and a caller
+ * stream), the library makes the new stream wait for the previous launch with
+ * an event (device-side, no host synchronisation).  To overlap frames, use one
+ * handle per stream (bench.py does).  The caller still orders its own use of
+ * d_out and d_counters across streams. */
 int rayhs_render_device(const rayhs_scene *scene, const rayhs_camera *camera,
                         const rayhs_render_params *params, void *d_out, void *hip_stream,
                         uint64_t *d_counters);
 
 /* Same as rayhs_render_device, and records two caller-owned HIP events (hipEvent_t, may be NULL) on the
  * stream immediately before and after the TRACE kernel alone (not the ticket reset, not the resolve
- * pass), so that a caller can time exactly the kernel a profiler reports. */
+ * pass), so that a caller can time exactly the kernel a profiler reports.  When the params select no rows
+ * nothing is launched and both events are recorded back to back. */
 int rayhs_render_device_events(const rayhs_scene *scene, const rayhs_camera *camera,
                                const rayhs_render_params *params, void *d_out, void *hip_stream,
                                uint64_t *d_counters, void *ev_before_trace, void *ev_after_trace);

@@ -74,6 +74,16 @@ struct rayhs_scene {
     mutable size_t order_cap = 0;
     mutable bool order_valid = false;            // order_dev holds an order for order_key
     mutable int order_key[10] = {0};             // frame geometry the order and the costs belong to
+    // One set of launch state (continuation workspace, sample buffer, tile costs / order) per handle: launches of one
+    // handle must not overlap.  On one stream they cannot; when the caller switches streams the new stream is made to
+    // wait for the previous launch (include/rayhs.h, "streams").
+    mutable hipStream_t last_stream = nullptr;
+    mutable hipEvent_t last_done = nullptr;      // recorded behind the last kernel of every launch
+    mutable bool have_last = false;
+    // rayhs_render (host-buffer entry point): device frame and timing events kept between calls
+    mutable void *host_out_dev = nullptr;
+    mutable size_t host_out_bytes = 0;
+    mutable hipEvent_t host_e0 = nullptr, host_e1 = nullptr;
 };
 
 extern "C" const char *rayhs_last_error(void) { return g_error.c_str(); }
@@ -92,6 +102,23 @@ static int check_desc(const rayhs_scene_desc *d, int &tree_depth) {
     // the kernels address records as base + 32-bit byte offset (largest record: 128 B per triangle, 64 B per node)
     if (d->n_tris > (1 << 25) || d->n_nodes > (1 << 25))
         return set_error(RAYHS_ERR_INVALID, "scene too large: at most 2^25 triangles and tree nodes are supported");
+    // an array may be NULL only when its count is zero
+    struct { const void *p; int64_t n; const char *name; } arrays[] = {
+        {d->obj_geom_kind, d->n_objects, "obj_geom_kind"}, {d->obj_geom_index, d->n_objects, "obj_geom_index"},
+        {d->mat_kind, d->n_objects, "mat_kind"}, {d->mat_ior, d->n_objects, "mat_ior"}, {d->mat_ce, d->n_objects, "mat_ce"},
+        {d->cmap_kind, d->n_objects, "cmap_kind"}, {d->cmap_c1, d->n_objects, "cmap_c1"}, {d->cmap_c2, d->n_objects, "cmap_c2"},
+        {d->cmap_size, d->n_objects, "cmap_size"}, {d->texels, d->n_texels, "texels"},
+        {d->plane_point, d->n_planes, "plane_point"}, {d->plane_normal, d->n_planes, "plane_normal"}, {d->plane_tangent, d->n_planes, "plane_tangent"},
+        {d->sphere_center, d->n_spheres, "sphere_center"}, {d->sphere_radius, d->n_spheres, "sphere_radius"},
+        {d->mesh_root, d->n_meshes, "mesh_root"}, {d->node_lo, d->n_nodes, "node_lo"}, {d->node_hi, d->n_nodes, "node_hi"},
+        {d->node_left, d->n_nodes, "node_left"}, {d->node_right, d->n_nodes, "node_right"}, {d->node_first_tri, d->n_nodes, "node_first_tri"},
+        {d->node_tri_count, d->n_nodes, "node_tri_count"}, {d->node_axis, d->n_nodes, "node_axis"},
+        {d->tri_pos, d->n_tris, "tri_pos"}, {d->tri_nrm, d->n_tris, "tri_nrm"}, {d->tri_uv, d->n_tris, "tri_uv"},
+        {d->light_kind, d->n_lights, "light_kind"}, {d->light_vec, d->n_lights, "light_vec"}, {d->light_color, d->n_lights, "light_color"},
+        {d->light_radius, d->n_lights, "light_radius"}};
+    for (const auto &a : arrays)
+        if (a.n > 0 && a.p == nullptr) return set_error(RAYHS_ERR_INVALID, "%s is NULL but its count is %lld", a.name, (long long)a.n);
+    if (d->n_texels < 0) return set_error(RAYHS_ERR_INVALID, "negative count in scene description");
     for (int i = 0; i < d->n_objects; i++) {
         int k = d->obj_geom_kind[i], g = d->obj_geom_index[i];
         int lim = k == RAYHS_GEOM_PLANE ? d->n_planes : k == RAYHS_GEOM_SPHERE ? d->n_spheres : k == RAYHS_GEOM_MESH ? d->n_meshes : -1;
@@ -99,6 +126,7 @@ static int check_desc(const rayhs_scene_desc *d, int &tree_depth) {
         if (d->mat_kind[i] < 0 || d->mat_kind[i] > RAYHS_MAT_SHOWUV) return set_error(RAYHS_ERR_INVALID, "object %d: bad material kind", i);
         if (d->cmap_kind[i] < 0 || d->cmap_kind[i] > RAYHS_CMAP_TEXTURE) return set_error(RAYHS_ERR_INVALID, "object %d: bad colour map kind", i);
         if (d->cmap_kind[i] == RAYHS_CMAP_TEXTURE && (d->mat_kind[i] == RAYHS_MAT_DIFFUSE || d->mat_kind[i] == RAYHS_MAT_PLASTIC)) {
+            if (!d->tex_w || !d->tex_h || !d->tex_offset) return set_error(RAYHS_ERR_INVALID, "object %d: texture colour map but tex_w / tex_h / tex_offset is NULL", i);
             int64_t n = (int64_t)d->tex_w[i] * d->tex_h[i];
             if (d->tex_w[i] <= 0 || d->tex_h[i] <= 0 || d->tex_offset[i] < 0 || d->tex_offset[i] + n > d->n_texels)
                 return set_error(RAYHS_ERR_INVALID, "object %d: texture outside the texel array", i);
@@ -383,6 +411,10 @@ extern "C" void rayhs_scene_destroy(rayhs_scene *s) {
     if (s->sbuf) (void)hipFree(s->sbuf);
     if (s->tickets) (void)hipFree(s->tickets);
     if (s->counters) (void)hipFree(s->counters);
+    if (s->host_out_dev) (void)hipFree(s->host_out_dev);
+    if (s->last_done) (void)hipEventDestroy(s->last_done);
+    if (s->host_e0) (void)hipEventDestroy(s->host_e0);
+    if (s->host_e1) (void)hipEventDestroy(s->host_e1);
     delete s;
 }
 
@@ -448,9 +480,11 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     dp.stripe_shift = log2_exact(p->stripe_rows);
     dp.tiles_x = (p->width + 7) / 8;
     dp.inv_tiles_x = 1.0f / (float)dp.tiles_x;
-    dp.n_tiles = dp.tiles_x * ((rows + 7) / 8);
     // the refill finds a tile's row and column with a float reciprocal plus one correction step (trace_kernel.hip)
-    if (dp.n_tiles >= (1 << 24) || rows >= (1 << 23)) return set_error(RAYHS_ERR_UNSUPPORTED, "frame too large: %d tiles of 8x8 pixels (limit 2^24)", dp.n_tiles);
+    const int64_t n_tiles64 = (int64_t)dp.tiles_x * (int64_t)((rows + 7) / 8);  // checked before narrowing: a very wide frame overflows int
+    if (n_tiles64 >= ((int64_t)1 << 24) || rows >= (1 << 23))
+        return set_error(RAYHS_ERR_UNSUPPORTED, "frame too large: %lld tiles of 8x8 pixels (limit 2^24)", (long long)n_tiles64);
+    dp.n_tiles = (int)n_tiles64;
     exact = (p->flags & RAYHS_FLAG_FMA) == 0;
     // kernel variants: 0 fast (16-bit stack entries, < 65536 BVH nodes), 3 fast (32-bit entries),
     // 1 counting, 2 exhaustive + counting (the reference's tree)
@@ -553,8 +587,16 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
     if (rc) return rc;
     if (!d_out) return set_error(RAYHS_ERR_INVALID, "d_out is NULL");
     if ((variant == 1 || variant == 2) && !d_counters) return set_error(RAYHS_ERR_INVALID, "RAYHS_FLAG_COUNT needs d_counters");
-    if (dp.n_tiles == 0) return RAYHS_OK;
     HIP_TRY(hipSetDevice(s->device));
+    if (dp.n_tiles == 0) {  // nothing to trace: the caller's events still get recorded, so that it can wait on / time them
+        if (e0) HIP_TRY(hipEventRecord(e0, st));
+        if (e1) HIP_TRY(hipEventRecord(e1, st));
+        return RAYHS_OK;
+    }
+    // launches of one handle share its workspace and tile-order buffers: a launch on another stream than the previous
+    // one first waits for that one to finish (device-side wait, no host synchronisation)
+    if (!s->last_done) HIP_TRY(hipEventCreateWithFlags(&s->last_done, hipEventDisableTiming));
+    if (s->have_last && s->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, s->last_done, 0));
     if ((rc = ensure_workspace(s, dp))) return rc;
     bool record_costs = false;
     if ((rc = plan_tile_order(s, p, variant, dp, record_costs))) return rc;
@@ -576,6 +618,8 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
                   : launch_resolve_fast(st, s->sbuf, d_out, dp.n_rows * dp.width, dp.spp, dp.out_format);
         if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "resolve kernel launch failed: %s", hipGetErrorString(e));
     }
+    HIP_TRY(hipEventRecord(s->last_done, st));
+    s->last_stream = st; s->have_last = true;
     return RAYHS_OK;
 }
 
@@ -597,41 +641,38 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
     HIP_TRY(hipSetDevice(s->device));
     size_t esz = p->out_format == RAYHS_OUT_F64 ? 8 : p->out_format == RAYHS_OUT_F32 ? 4 : 2;
     size_t bytes = (size_t)rows * (size_t)p->width * 3 * esz;
-    void *d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_out, std::max<size_t>(bytes, 16)));
+    // the device frame and the two timing events live with the handle (grow-only): repeated calls allocate nothing
+    if (bytes > s->host_out_bytes || !s->host_out_dev) {
+        if (s->host_out_dev) HIP_TRY(hipFree(s->host_out_dev));
+        s->host_out_dev = nullptr; s->host_out_bytes = 0;
+        HIP_TRY(hipMalloc(&s->host_out_dev, std::max<size_t>(bytes, 16)));
+        s->host_out_bytes = std::max<size_t>(bytes, 16);
+    }
+    if (!s->host_e0) HIP_TRY(hipEventCreate(&s->host_e0));
+    if (!s->host_e1) HIP_TRY(hipEventCreate(&s->host_e1));
     const bool count = (p->flags & RAYHS_FLAG_COUNT) != 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    int rc = RAYHS_OK;
-    hipError_t he = hipSuccess;
-    do {
-        if (count && (he = hipMemset(s->counters, 0, sizeof(unsigned long long) * CNT_SLOTS)) != hipSuccess) break;
-        if ((he = hipEventCreate(&e0)) != hipSuccess || (he = hipEventCreate(&e1)) != hipSuccess) break;
-        rc = launch(s, cam, p, d_out, nullptr, count ? (uint64_t *)s->counters : nullptr, e0, e1);
-        if (rc) break;
-        if ((he = hipDeviceSynchronize()) != hipSuccess) break;
-        if (bytes && (he = hipMemcpy(out_host, d_out, bytes, hipMemcpyDeviceToHost)) != hipSuccess) break;
-        if (stats) {
-            std::memset(stats, 0, sizeof *stats);
-            float ms = 0;
-            if (bytes && (he = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) break;
-            stats->kernel_ms = ms;
-            if (count) {
-                unsigned long long c[CNT_SLOTS];
-                if ((he = hipMemcpy(c, s->counters, sizeof c, hipMemcpyDeviceToHost)) != hipSuccess) break;
-                stats->rays_primary = c[CNT_PRIMARY]; stats->rays_reflect = c[CNT_REFLECT]; stats->rays_refract = c[CNT_REFRACT];
-                stats->rays_refract_exit = c[CNT_REFRACT_EXIT]; stats->rays_shadow = c[CNT_SHADOW];
-                stats->nodes_tested = c[CNT_NODES]; stats->tris_tested = c[CNT_TRIS]; stats->prims_tested = c[CNT_PRIMS];
-                stats->shaded_hits = c[CNT_SHADED]; stats->pixels = c[CNT_PIXELS] / (unsigned long long)std::max(p->spp, 1);  // the kernel counts samples
-                if (std::getenv("RAYHS_DEBUG_COUNTERS"))  // development: raw loop counters of a -DRAYHS_PROFILE_LOOPS build
-                    std::fprintf(stderr, "rayhs adv[0..3] %llu %llu %llu %llu span_ticks %llu latest_end %llu earliest_start %llu counters[6..15]: %llu %llu | %llu %llu | %llu %llu %llu %llu %llu %llu  kernel_ms %.3f\n", c[0], c[1], c[2], c[3], c[5] - ~c[4], c[5], ~c[4], c[6], c[7], c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], (double)ms);
-            }
-        }
-    } while (0);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    (void)hipFree(d_out);
+    if (count) HIP_TRY(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * CNT_SLOTS, nullptr));
+    int rc = launch(s, cam, p, s->host_out_dev, nullptr, count ? (uint64_t *)s->counters : nullptr, s->host_e0, s->host_e1);
     if (rc) return rc;
-    if (he != hipSuccess) return set_error(RAYHS_ERR_HIP, "HIP call failed in rayhs_render: %s", hipGetErrorString(he));
+    // the copy is ordered behind the kernels on the NULL stream and blocks the host until the frame is there
+    if (bytes) HIP_TRY(hipMemcpy(out_host, s->host_out_dev, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->host_e0, s->host_e1));
+        stats->kernel_ms = ms;
+        if (count) {
+            unsigned long long c[CNT_SLOTS];
+            HIP_TRY(hipMemcpy(c, s->counters, sizeof c, hipMemcpyDeviceToHost));
+            stats->rays_primary = c[CNT_PRIMARY]; stats->rays_reflect = c[CNT_REFLECT]; stats->rays_refract = c[CNT_REFRACT];
+            stats->rays_refract_exit = c[CNT_REFRACT_EXIT]; stats->rays_shadow = c[CNT_SHADOW];
+            stats->nodes_tested = c[CNT_NODES]; stats->tris_tested = c[CNT_TRIS]; stats->prims_tested = c[CNT_PRIMS];
+            stats->shaded_hits = c[CNT_SHADED]; stats->pixels = c[CNT_PIXELS] / (unsigned long long)std::max(p->spp, 1);  // the kernel counts samples
+            if (std::getenv("RAYHS_DEBUG_COUNTERS"))  // development: raw loop counters of a -DRAYHS_PROFILE_LOOPS build
+                std::fprintf(stderr, "rayhs adv[0..3] %llu %llu %llu %llu span_ticks %llu latest_end %llu earliest_start %llu counters[6..15]: %llu %llu | %llu %llu | %llu %llu %llu %llu %llu %llu  kernel_ms %.3f\n", c[0], c[1], c[2], c[3], c[5] - ~c[4], c[5], ~c[4], c[6], c[7], c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], (double)ms);
+        }
+    }
     return RAYHS_OK;
 }
 

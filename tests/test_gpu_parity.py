@@ -41,12 +41,22 @@ def _native_library_loaded():
 
 
 # ------------------------------------------------ fixtures and oracle, bit-exact
+# Every oracle / fixture comparison runs on the kernels that SHIP (flags 0: rayhs_trace_exact, or rayhs_trace_wide_exact
+# for scenes with >= 65536 nodes) as well as on the instrumented variant (FLAG_COUNT: rayhs_trace_count_exact, whose
+# work counters are compared too).  The reference-path replay and the shadow-query shortcut live in both.
+PRODUCTION, COUNTING = 0, L.FLAG_COUNT
+BOTH_KERNELS = pytest.mark.parametrize("flags", [PRODUCTION, COUNTING], ids=["production", "counting"])
+
+
+@BOTH_KERNELS
 @pytest.mark.parametrize("name", ["cornell_96", "dragon_superlow_96", "dragon_superlow_96_spp4", "transform_64"])
-def test_bit_exact_against_golden_and_oracle(name):
+def test_bit_exact_against_golden_and_oracle(name, flags):
     m = META[name]
-    img, st = rayhs_amd.ray_trace_file(m["scene"], spp=m["spp"], seed=m["seed"], flags=L.FLAG_COUNT)
+    img, st = rayhs_amd.ray_trace_file(m["scene"], spp=m["spp"], seed=m["seed"], flags=flags)
     gold = np.load(os.path.join(GOLD, name + ".npy"))
     assert img.dtype == np.float64 and np.array_equal(img, gold)
+    if flags == PRODUCTION:
+        return
     assert st["pixels"] == m["width"] * m["height"]
     for k in ("rays_primary", "rays_reflect", "rays_refract", "rays_refract_exit", "rays_shadow", "shaded_hits"):
         assert st[k] == m["stats"][k], k          # same rays, whatever the traversal order
@@ -69,9 +79,11 @@ def test_scenes_with_sphere_uv_within_tolerance(name):
                                            ("scenes/dragon_low_1080p.json", 120, 68, 4), ("data/transform.json", 77, 53, 2)])
 def test_bit_exact_against_oracle_at_other_sizes(scene, w, h, spp):
     want, ost = oracle_image(scene, width=w, height=h, spp=spp)
-    got, st = rayhs_amd.ray_trace_file(scene, width=w, height=h, spp=spp, flags=L.FLAG_COUNT)
+    got, st = rayhs_amd.ray_trace_file(scene, width=w, height=h, spp=spp, flags=COUNTING)
     assert np.array_equal(got, want)
     assert st["rays"] == ost["rays"]
+    got, _ = rayhs_amd.ray_trace_file(scene, width=w, height=h, spp=spp, flags=PRODUCTION)
+    assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("spp", [2, 3, 5, 8, 16, 32, 64, 96])
@@ -120,11 +132,19 @@ def _scene_json(objects, lights, w=16, h=12, depth=2, cam_z=-2.0, proj="perspect
                        "scene": {"objects": objects, "lights": lights}})
 
 
+def _same(a, b):
+    return a.shape == b.shape and bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+
+
 def _both(text, tmp_path, **kw):
+    """Oracle image + the image of the PRODUCTION kernel; the counting kernel supplies the work counters and must
+    produce the same image bit for bit (so every caller's comparison with the oracle covers both kernels)."""
     p = tmp_path / "s.json"
     p.write_text(text)
     want, ost = oracle_image(str(p), **kw)
-    got, st = rayhs_amd.ray_trace_file(str(p), flags=L.FLAG_COUNT, **kw)
+    counted, st = rayhs_amd.ray_trace_file(str(p), flags=COUNTING, **kw)
+    got, _ = rayhs_amd.ray_trace_file(str(p), flags=PRODUCTION, **kw)
+    assert _same(got, counted), ("production and counting kernels differ", int((got != counted).any(axis=2).sum()))
     return got, want, st, ost
 
 
@@ -246,6 +266,54 @@ def test_device_entry_point_renders_into_a_torch_tensor_on_its_stream():
     r.close()
 
 
+def test_one_handle_alternating_between_two_streams_and_the_host_entry_point():
+    # A handle has ONE launch workspace and ONE tile-cost / order buffer.  Launches enqueued on different
+    # non-blocking streams (and through rayhs_render's NULL stream) would share them if they overlapped; the
+    # library chains them with an event (include/rayhs.h, "Streams").  Every frame must be the single-stream image.
+    import torch
+    r = build_rendering("scenes/dragon_low_1080p.json")
+    w, h = r.width, r.height
+    want, _ = r.ray_trace(spp=2, out_format=L.OUT_F32)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0") for _ in range(6)]
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):                 # no host sync between the enqueues
+        st = (s1, s2)[i % 2]
+        r.ray_trace_device(o.data_ptr(), st.cuda_stream, spp=2, out_format=L.OUT_F32)
+    mixed, _ = r.ray_trace(spp=2, out_format=L.OUT_F32)      # NULL stream right behind them
+    torch.cuda.synchronize()
+    assert np.array_equal(mixed, want)
+    for i, o in enumerate(outs):
+        assert np.array_equal(o.cpu().numpy(), want), i
+    r.close()
+
+
+def test_frame_wider_than_the_tile_limit_is_refused_not_wrapped():
+    # tiles_x * tile rows is formed in 64 bits: 2^27 x 16 tiles would wrap a 32-bit product to a negative count
+    r = build_rendering("scenes/cornell_96.json", width=1 << 30, height=128)
+    with pytest.raises(L.RayhsError) as e:
+        r.ray_trace_device(0x1000, 0, out_format=L.OUT_F32)
+    assert e.value.code == L.ERR_UNSUPPORTED and "frame too large" in e.value.message
+    r.close()
+
+
+def test_empty_row_selection_records_the_callers_events():
+    import torch
+    r = build_rendering("scenes/cornell_96.json")
+    out = torch.zeros(16, dtype=torch.float32, device="cuda:0")
+    s = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    e1.record(s)
+    torch.cuda.synchronize()
+    r.ray_trace_device(out.data_ptr(), s.cuda_stream, events=(e0.cuda_event, e1.cuda_event), row0=10, row1=10, out_format=L.OUT_F32)
+    torch.cuda.synchronize()
+    assert 0.0 <= e0.elapsed_time(e1) < 100.0
+    img, st = r.ray_trace(row0=10, row1=10)
+    assert img.shape == (0, 96, 3)
+    r.close()
+
+
 # ------------------------------------------------- BASELINE sizes: properties
 @pytest.mark.parametrize("scene,spp", [("scenes/cornell_1080p_d0.json", 1), ("scenes/dragon_low_1080p.json", 4)])
 def test_full_size_properties(scene, spp):
@@ -298,6 +366,79 @@ def test_headline_scene_band_against_oracle():
     part, _ = r.ray_trace(spp=16, row0=600, row1=602)
     want, _ = oracle_image(scene, spp=16, row0=600, row1=602)
     assert np.array_equal(part, want)
+    r.close()
+
+
+# ---------------------------------------- BASELINE configs: WHOLE frames, production kernels
+# tests/golden/frame_digests.json holds sha256 + exact per-row sums of the oracle's full frames of configs[1]..[4]
+# (tests/golden/make_frame_digests.py, run once in the build container: the 4K / 64 spp frame is 2.5 G rays).
+DIGESTS = json.load(open(os.path.join(GOLD, "frame_digests.json")))
+
+
+def _assert_frame_matches_digest(img, name):
+    import hashlib
+    import math
+    d = DIGESTS[name]
+    assert img.shape == (d["height"], d["width"], 3)
+    key = "sha256_f64" if img.dtype == np.float64 else "sha256_f32"
+    if hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == d[key]:
+        return
+    bad = [y for y in range(img.shape[0]) if math.fsum(img[y].astype(np.float64).ravel().tolist()).hex() != d["row_fsum"][y]] \
+        if img.dtype == np.float64 else "(fp32 frame: rows not located)"
+    raise AssertionError(f"{name}: frame differs from the oracle's digest; rows {bad if isinstance(bad, str) else bad[:20]}")
+
+
+@pytest.mark.parametrize("name", ["cornell", "dragon_low", "dragon"])
+def test_whole_baseline_frames_equal_the_oracle_digests(name):
+    # configs[1]..[3] at their own size and sample count, every pixel: the production kernel's first frame (scan
+    # order), its second (tiles re-ordered by measured cost), the fp32 frame bench.py renders, and the ray counts
+    d = DIGESTS[name]
+    r = build_rendering(d["scene"])
+    for _ in range(2):
+        img, _ = r.ray_trace(spp=d["spp"], seed=d["seed"])
+        _assert_frame_matches_digest(img, name)
+    f32, _ = r.ray_trace(spp=d["spp"], seed=d["seed"], out_format=L.OUT_F32)
+    _assert_frame_matches_digest(f32, name)
+    _, st = r.ray_trace(spp=d["spp"], seed=d["seed"], flags=COUNTING)
+    for k in ("rays_primary", "rays_reflect", "rays_refract", "rays_refract_exit", "rays_shadow", "shaded_hits", "rays"):
+        assert st[k] == d["stats"][k], k
+    r.close()
+
+
+def test_headline_frame_whole_against_the_live_oracle_and_the_exhaustive_kernel():
+    # configs[3] (the bench default): all 1920 x 1080 pixels at 16 spp against the oracle run here and now
+    # (seconds on the box's host cores), and against the exhaustive kernel that walks the reference's own tree
+    scene = "scenes/dragon_1080p.json"
+    want, ost = oracle_image(scene, spp=16)
+    _assert_frame_matches_digest(want, "dragon")           # the committed digest is this oracle's
+    r = build_rendering(scene)
+    got, _ = r.ray_trace(spp=16)
+    assert np.array_equal(got, want), int((got != want).any(axis=2).sum())
+    exh, st = r.ray_trace(spp=16, flags=L.FLAG_COUNT | L.FLAG_EXHAUSTIVE)
+    assert np.array_equal(exh, want)
+    assert st["rays"] == ost["rays"]
+    r.close()
+
+
+def test_4k_64spp_whole_frame_bands_and_eight_rank_stripes():
+    # configs[4] at its own sample count: the whole 3840 x 2160 / 64 spp frame against the committed oracle digest,
+    # 16 two-row bands against the live oracle, and the 8-rank stripe decomposition reassembled
+    d = DIGESTS["dragon4k"]
+    scene, spp = d["scene"], d["spp"]
+    assert spp == 64 and (d["width"], d["height"]) == (3840, 2160)
+    r = build_rendering(scene)
+    h = r.height
+    full, _ = r.ray_trace(spp=spp)
+    _assert_frame_matches_digest(full, "dragon4k")
+    for i in range(16):
+        y0 = min(h - 2, int((i + 0.5) * h / 16))
+        want, _ = oracle_image(scene, spp=spp, row0=y0, row1=y0 + 2)
+        assert np.array_equal(full[y0:y0 + 2], want), y0
+    whole = np.empty_like(full)
+    for rank in range(8):
+        part, _ = r.ray_trace(spp=spp, stripe_rows=8, stripe_rank=rank, stripe_count=8)
+        whole[tiles.stripe_rows_of(rank, 8, h, 8)] = part
+    assert np.array_equal(whole, full)
     r.close()
 
 
@@ -513,10 +654,15 @@ def test_rays_through_mesh_vertices_and_edges(tmp_path):
     p = tmp_path / "s.json"
     p.write_text(json.dumps(scene))
     want, ost = oracle_image(str(p))
-    got, st = rayhs_amd.ray_trace_file(str(p), flags=L.FLAG_COUNT)
+    got, st = rayhs_amd.ray_trace_file(str(p), flags=COUNTING)
     exh, _ = rayhs_amd.ray_trace_file(str(p), flags=L.FLAG_COUNT | L.FLAG_EXHAUSTIVE)
     assert np.array_equal(exh, want)
     assert np.array_equal(got, want), (np.abs(got - want).max(), int((got != want).any(axis=2).sum()))
+    r = build_rendering(str(p))                      # the production kernel: scan order, then (were the frame large enough) re-ordered
+    for _ in range(2):
+        prod, _ = r.ray_trace()
+        assert np.array_equal(prod, want), (np.abs(prod - want).max(), int((prod != want).any(axis=2).sum()))
+    r.close()
     assert st["rays"] == ost["rays"] and (want > 0).any(axis=2).mean() > 0.9     # the field really is hit everywhere
 
 

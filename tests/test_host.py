@@ -295,6 +295,26 @@ def test_scene_desc_validation_rejects_broken_trees():
     assert b"object 0" in L.load().rayhs_last_error()
 
 
+def test_scene_desc_validation_rejects_null_arrays_with_a_positive_count():
+    # every array whose count is > 0 must be there: checked before anything is dereferenced (and before the device is)
+    import copy
+    rd = RenderDesc("scenes/dragon_superlow_96.json")
+    h = C.c_void_p()
+    for field in ("mat_kind", "mat_ior", "cmap_kind", "cmap_c1", "plane_normal", "sphere_radius", "mesh_root", "node_lo",
+                  "node_tri_count", "node_axis", "tri_pos", "tri_uv", "light_kind", "light_radius", "obj_geom_index"):
+        d = L.SceneDesc.from_buffer_copy(rd.scene_desc)
+        setattr(d, field, type(getattr(d, field))())      # NULL
+        assert L.load().rayhs_scene_create(C.byref(d), 0, C.byref(h)) == L.ERR_INVALID, field
+        assert field.encode() in L.load().rayhs_last_error(), field
+    d = L.SceneDesc.from_buffer_copy(rd.scene_desc)       # a NULL array with a zero count is fine (here: no spheres, no lights)
+    d.n_lights = 0
+    d.light_kind = type(d.light_kind)()
+    rc = L.load().rayhs_scene_create(C.byref(d), 0, C.byref(h))
+    assert rc in (L.OK, L.ERR_NO_DEVICE)
+    if rc == L.OK:
+        L.load().rayhs_scene_destroy(h)
+
+
 # ------------------------------------------------------------- params / output
 def test_render_rows_follows_the_stripe_rule():
     from rayhs_amd import tiles
