@@ -9,8 +9,10 @@ interleaved 8-row stripes with the HIP kernel (scene resident in HBM, output in
 an HBM buffer), then the rows are gathered to rank 0 (one RCCL gather) and
 assembled.  `value` = rays of all ranks / wall time of K steps (max over ranks,
 barrier + synchronize on both sides).  A ray = one scene query
-(closestIntersection or shadowIntersection); rays per frame come
-from one untimed instrumented run of the same kernel.  The frame is fixed, so
+(closestIntersection or shadowIntersection) that was actually
+traced; rays per frame come from one untimed instrumented run of the same kernel
+(`reference_rays_per_frame` also counts the shadow queries of the reference that
+are provably irrelevant -- zero light term -- and therefore skipped).  The frame is fixed, so
 scaling is "strong".
 
 Extra objects on the JSON line:
@@ -199,14 +201,17 @@ def main():
     r.ray_trace_device(g.local.data_ptr(), stream.cuda_stream, counters.data_ptr(), flags=flags | L.FLAG_COUNT, **kw)
     torch.cuda.synchronize()
     names = ["rays_primary", "rays_reflect", "rays_refract", "rays_refract_exit", "rays_shadow", "nodes_tested", "tris_tested",
-             "prims_tested", "shaded_hits", "pixels"]
+             "prims_tested", "shaded_hits", "pixels", "shadow_skipped"]
     counters[9] //= spp  # the kernel counts finished samples; pixels = samples / spp
-    mine = dict(zip(names, counters[:10].tolist()))
+    mine = dict(zip(names, counters[:11].tolist()))
     total = counters.clone()
     if world > 1:
         dist.all_reduce(total)
-    tot = dict(zip(names, total[:10].tolist()))
-    rays_frame = sum(v for k, v in tot.items() if k.startswith("rays_"))
+    tot = dict(zip(names, total[:11].tolist()))
+    # rays_* count the REFERENCE's scene queries of the frame; shadow queries whose light term is exactly zero are not
+    # traced at all (trace_kernel.hip, light section) and are NOT counted in `value`
+    reference_rays_frame = sum(v for k, v in tot.items() if k.startswith("rays_"))
+    rays_frame = reference_rays_frame - tot["shadow_skipped"]
 
     # set-up, like the instrumented run above: the first frame a scene handle renders runs in scan order and measures
     # the chunk times that order every later frame; the warm-up and timed steps are steady state
@@ -272,7 +277,8 @@ def main():
                        "kernels": "fma" if args.fma else "exact (-ffp-contract=off, bit-identical to the CPU oracle)",
                        "scheduling": "tiles handed out slowest-first, from the chunk times the previous frame measured (ordering kernel inside every step)"},
             "mpixels_per_s": w * h * args.steps / dt / 1e6,
-            "rays_per_frame": rays_frame, "kernel_ms_rank0": kernel_ms, "first_frame_ms": first_frame_ms,
+            "rays_per_frame": rays_frame, "reference_rays_per_frame": reference_rays_frame,
+            "kernel_ms_rank0": kernel_ms, "first_frame_ms": first_frame_ms,
             "verified_against_single_rank": verified,
             "verified_against_oracle": {"whole_frame_sha256_equals_oracle_digest": golden_ok, "rows_against_live_oracle": None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

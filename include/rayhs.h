@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RAYHS_ABI_VERSION 1
+#define RAYHS_ABI_VERSION 2
 
 typedef enum {
     RAYHS_OK = 0,
@@ -146,9 +146,10 @@ typedef struct rayhs_render_params {
     uint32_t flags;     /* RAYHS_FLAG_* */
 } rayhs_render_params;
 
-/* One ray = one scene query: closestIntersection (src/RayHs.hs:67) or
- * shadowIntersection (src/RayHs.hs:74).  Work counters are filled only with
- * RAYHS_FLAG_COUNT. */
+/* One ray = one scene query of the reference: closestIntersection
+ * (src/RayHs.hs:67) or shadowIntersection (src/RayHs.hs:74).  rays_* count the
+ * reference's queries; rays actually traced = their sum - shadow_skipped.
+ * Work counters are filled only with RAYHS_FLAG_COUNT. */
 typedef struct rayhs_stats {
     uint64_t rays_primary, rays_reflect, rays_refract, rays_refract_exit, rays_shadow;
     uint64_t nodes_tested;  /* rayInterBox evaluations (src/KDTree.hs:39) */
@@ -157,6 +158,8 @@ typedef struct rayhs_stats {
     uint64_t shaded_hits;   /* irradiance evaluations (src/RayHs.hs:107) */
     uint64_t pixels;        /* pixels written */
     double kernel_ms;       /* HIP-event time of the trace kernel of this call (host-buffer entry point only) */
+    uint64_t shadow_skipped; /* of rays_shadow: queries of the reference that were NOT traced because the light's diffuse
+                              * term was exactly zero, so occluded or not the pixel is the same (ABI version 2) */
 } rayhs_stats;
 
 typedef struct rayhs_scene rayhs_scene;

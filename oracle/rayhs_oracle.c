@@ -349,7 +349,12 @@ static int shadow_intersection(ctx *cx, const orc_scene *s, const light *l, ray 
 
 /* ------------------------------------------------------ Material / ColorMap */
 static double sq(double x) { return x * x; }              /* GHC (^) with exponent 2 */
-static double pow5(double x) { double x2 = x * x; return (x2 * x2) * x; } /* GHC (^) with exponent 5 */
+/* x ^ (5 :: Int) as GHC compiles it with optimisation on (build.sh:1 uses -O2): GHC.Real carries the rewrite
+ * RULES "^2/Int" .. "^5/Int" (GHC ticket #5237), which turn a literal small Int exponent into the FLAT
+ * left-associated product u*u*u*u*u; only an un-optimised build runs the square-and-multiply definition
+ * ((x*x)*(x*x))*x.  The two differ by at most an ulp or two of the Fresnel factor.  [from memory of base's
+ * GHC/Real.hs -- no GHC here to confirm; DESIGN.md section 2] */
+static double pow5(double x) { return x * x * x * x * x; }
 double orc_r0(double n1, double n2) { return sq((n1 - n2) / (n1 + n2)); }  /* Material.hs:22-24 */
 double orc_fresnel(double ior, double cos0) {                              /* Material.hs:26-29 */
     double r = orc_r0(1.0, ior);

@@ -668,6 +668,7 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
             stats->rays_primary = c[CNT_PRIMARY]; stats->rays_reflect = c[CNT_REFLECT]; stats->rays_refract = c[CNT_REFRACT];
             stats->rays_refract_exit = c[CNT_REFRACT_EXIT]; stats->rays_shadow = c[CNT_SHADOW];
             stats->nodes_tested = c[CNT_NODES]; stats->tris_tested = c[CNT_TRIS]; stats->prims_tested = c[CNT_PRIMS];
+            stats->shadow_skipped = c[CNT_SHADOW_SKIPPED];
             stats->shaded_hits = c[CNT_SHADED]; stats->pixels = c[CNT_PIXELS] / (unsigned long long)std::max(p->spp, 1);  // the kernel counts samples
             if (std::getenv("RAYHS_DEBUG_COUNTERS"))  // development: raw loop counters of a -DRAYHS_PROFILE_LOOPS build
                 std::fprintf(stderr, "rayhs adv[0..3] %llu %llu %llu %llu span_ticks %llu latest_end %llu earliest_start %llu counters[6..15]: %llu %llu | %llu %llu | %llu %llu %llu %llu %llu %llu  kernel_ms %.3f\n", c[0], c[1], c[2], c[3], c[5] - ~c[4], c[5], ~c[4], c[6], c[7], c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], (double)ms);

@@ -134,7 +134,10 @@ struct DParams {
 
 // counters[] slots
 enum { CNT_PRIMARY = 0, CNT_REFLECT, CNT_REFRACT, CNT_REFRACT_EXIT, CNT_SHADOW, CNT_NODES, CNT_TRIS,
-       CNT_PRIMS, CNT_SHADED, CNT_PIXELS, CNT_SLOTS = 16 };
+       CNT_PRIMS, CNT_SHADED, CNT_PIXELS,
+       CNT_SHADOW_SKIPPED,  // shadow queries counted in CNT_SHADOW but not traced (zero light term); slot 10 doubles as a
+                            // development counter in -DRAYHS_PROFILE_LOOPS / -DRAYHS_PROFILE_TIME builds
+       CNT_SLOTS = 16 };
 
 static constexpr int TRACE_BLOCK = 256;     // threads per workgroup (4 waves)
 static constexpr int FRAME_SLOTS = 14;      // doubles per continuation frame

@@ -43,15 +43,12 @@
 //     direction and the continuation frames of suspended irradiance calls live in a global workspace
 //     (slot-major so lanes coalesce).
 // Development switches: RAYHS_PROFILE_LOOPS / RAYHS_PROFILE_TIME (diagnostic builds with trip counters
-// or s_memtime stamps, read with RAYHS_DEBUG_COUNTERS=1), RAYHS_SLICE_MIN / RAYHS_REFILL_MIN /
-// RAYHS_CHUNK (scheduling experiments; the defaults are the measured optimum).
+// or s_memtime stamps, read with RAYHS_DEBUG_COUNTERS=1), RAYHS_REFILL_MIN / RAYHS_CHUNK (scheduling
+// experiments; the defaults are the measured optimum).
 #include <hip/hip_runtime.h>
 
 #include "device_scene.h"
 
-#ifndef RAYHS_SLICE_MIN
-#define RAYHS_SLICE_MIN 0   // leave the traversal loop when fewer lanes than this are still traversing (0: never early)
-#endif
 #ifndef RAYHS_REFILL_MIN
 #define RAYHS_REFILL_MIN 64 // idle lanes that trigger a refill.  64 = the wave refills as a whole: its 64 lanes then hold
                             // consecutive samples of the same few pixels and stay in lock-step (measured: 11.3 ms
@@ -150,11 +147,11 @@ template <class OB> DEV V3 color_at(const OB &o, const double *texels, double u,
     return add(scl(ly, cx1), scl(1 - ly, cx0));
 }
 
-// fresnel (src/Material.hs:26-29); r = r0 1.0 ior precomputed; (^5) = (x*x)*(x*x)*x as GHC's (^)
+// fresnel (src/Material.hs:26-29); r = r0 1.0 ior precomputed.  (^ (5 :: Int)) is the flat product u*u*u*u*u that
+// GHC's rewrite RULES "^5/Int" (GHC.Real) produce with optimisation on (build.sh:1: -O2), not square-and-multiply
 DEV double fresnel(double r, double cos0) {
     double x = 1 - cos0;
-    double x2 = x * x;
-    return r + (1 - r) * ((x2 * x2) * x);
+    return r + (1 - r) * ((((x * x) * x) * x) * x);
 }
 
 // splitmix64 finaliser: the build-defined counter sampler (include/rayhs.h, rayhs_sample01)
@@ -285,24 +282,20 @@ struct Tracer {
     bool bref;  // btri indexes the reference-order arrays (hit found by the reference tree), else the BVH-order ones
     bool occ;   // shadow query: an occluder was found
 
-    // resumable traversal state of the fast BVH (kept across time slices)
-    int t_m;               // next mesh to start once the current one is exhausted; n_meshes when none is left
+    bool armed; // begin() left the meshes of this lane's query to the fast BVH (traverse())
+
+    // traversal state of the fast BVH; lives only inside traverse()
     int t_cur, t_sp;       // current inner node (FNODE_NONE = none), stack depth
     int t_pa, t_pb;        // postponed leaves
-    int t_obj;             // scene object of the mesh being traversed
     float t_ax, t_ay, t_az, t_bx, t_by, t_bz;  // per-plane slab coefficients of the current mesh (see pbox)
     float t_enter;                             // shift of the traversal origin along the ray
 
-    __device__ __forceinline__ bool traversing() const {
-        return t_cur != FNODE_NONE || t_pa != FNODE_NONE || t_sp > 0 || t_m < sc.n_meshes;
-    }
-    __device__ __forceinline__ void stop_traversal() { t_cur = FNODE_NONE; t_pa = FNODE_NONE; t_pb = FNODE_NONE; t_sp = 0; t_m = sc.n_meshes; }
-    // without time slicing a query always ends inside slice(): say so to the register allocator
-    __device__ __forceinline__ void forget_traversal() { stop_traversal(); t_obj = 0; t_ax = t_ay = t_az = t_bx = t_by = t_bz = t_enter = 0; }
+    __device__ __forceinline__ bool traversing() const { return t_cur != FNODE_NONE || t_pa != FNODE_NONE || t_sp > 0; }
+    __device__ __forceinline__ void stop_traversal() { t_cur = FNODE_NONE; t_pa = FNODE_NONE; t_pb = FNODE_NONE; t_sp = 0; }
 
     __device__ Tracer(const DScene &s, stack_ptr st, Counters &c) : sc(s), stack(st), cnt(c) {
-        bt = 0; bu = 0; bv = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; occ = false;
-        t_obj = 0; t_ax = t_ay = t_az = t_bx = t_by = t_bz = t_enter = 0;
+        bt = 0; bu = 0; bv = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; occ = false; armed = false;
+        t_ax = t_ay = t_az = t_bx = t_by = t_bz = t_enter = 0;
         stop_traversal();
     }
 
@@ -412,12 +405,13 @@ struct Tracer {
     // Start one scene query for this lane (kind == Q_NONE: lane does not start one).  Q_CLOSEST fills
     // the b* record (bobj = -1 on a miss); Q_SHADOW sets `occ` if any non-Emmit object occludes the
     // light (src/RayHs.hs:74-87).  Planes, spheres and (for the rare rays that need it) the reference
-    // tree are finished here; the fast BVH traversal is only armed and runs in slice().
+    // tree are finished here; the fast BVH traversal is only armed and runs in traverse().
     __device__ void begin(int kind, const Ray &r, bool point_light, double light_d2) {
         const bool active = kind != Q_NONE;
         const bool shadow = kind == Q_SHADOW;
         bool occluded = false;
         if (active) { bt = __builtin_inf(); bu = 0; bv = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; }
+        armed = false;
 
         // ---- planes and spheres: wave-uniform loops, scene constants via scalar loads.  The per-lane
         // decisions are predicated selects, and the only branches are wave-level (ballot): nested per-lane
@@ -477,8 +471,8 @@ struct Tracer {
             const bool by_reference = EXH || !(fabs(r.d.x) > 1e-25) || !(fabs(r.d.y) > 1e-25) || !(fabs(r.d.z) > 1e-25);  // also keeps 1/d finite in fp32
             if (EXH || __ballot(active && by_reference) != 0ull)
                 occluded = meshes_reference(active && by_reference, shadow, r, point_light, light_d2, occluded);
-            // arm the fast traversal: slice() starts with mesh 0
-            if (!EXH && active && !by_reference && !(shadow && occluded)) t_m = 0;
+            // leave the meshes to the fast traversal
+            armed = !EXH && active && !by_reference && !(shadow && occluded);
         }
         if (active) occ = occluded;
     }
@@ -556,99 +550,97 @@ struct Tracer {
         t_sp = t_sp + (both ? 1 : 0) - (pop ? 1 : 0);
     }
 
-    // ---- fast BVH: fp32 conservative boxes, fp64 triangle tests, as a resumable time slice.
-    // A wave's query round would otherwise last as long as its slowest ray.  Instead the loop is left as
-    // soon as fewer than RAYHS_SLICE_MIN lanes are still traversing while some other lane could do useful
-    // work (shade, start its next ray, fetch a pixel); the traversal state above survives and the
-    // remaining lanes resume in the next slice together with the newly started rays.
-    __device__ void slice(bool shadow, const Ray &r, bool point_light, double light_d2, double light_dist, bool useful_when_free) {
+    // ---- fast BVH: fp32 conservative boxes, fp64 triangle tests.  Meshes are taken one at a time by the whole wave
+    // (the mesh record comes through the scalar cache, its object index and root stay in SGPRs); inside a mesh the
+    // lanes walk independently until the last one is done.
+    __device__ void traverse(bool shadow, const Ray &r, bool point_light, double light_d2, double light_dist) {
         if (EXH) return;
+        if (__ballot(armed) == 0ull) return;
         // reciprocal direction in fp32 (1 ulp): every use below is a conservative cull, never a result
         const float ix = __builtin_amdgcn_rcpf((float)r.d.x), iy = __builtin_amdgcn_rcpf((float)r.d.y), iz = __builtin_amdgcn_rcpf((float)r.d.z);
-        float limf = f32_up((shadow ? light_dist : bt) - (double)t_enter);
         TIME_DECL;
-        while (true) {
-            // start the next mesh for lanes that have exhausted the current one
-            while (t_cur == FNODE_NONE && t_pa == FNODE_NONE && t_sp == 0 && t_m < sc.n_meshes) {
-                const auto &me = rec(sc.meshes, t_m);
-                t_m++;
-                if (me.froot == FNODE_NONE || (shadow && !me.occluder)) continue;
-                const double lim = shadow ? light_dist : bt;
-                // root cull in mesh-centred fp32.  The origin may be far from the mesh, so its rounding error
-                // (2^-24 of its distance) is added to the box as an explicit margin.
-                const float cxo = (float)(r.o.x - me.center[0]), cyo = (float)(r.o.y - me.center[1]), czo = (float)(r.o.z - me.center[2]);
-                const float mg = 4.76837158e-7f * fmaxf(fmaxf(fabsf(cxo), fabsf(cyo)), fabsf(czo));  // 2^-21 * max |o - c|
-                float lo[3] = {me.flo[0] - mg, me.flo[1] - mg, me.flo[2] - mg};
-                float hi[3] = {me.fhi[0] + mg, me.fhi[1] + mg, me.fhi[2] + mg};
-                float tn_root;
-                if (COUNT) cnt.c[CNT_NODES]++;
-                if (!fbox(lo, hi, cxo, cyo, czo, ix, iy, iz, f32_up(lim), tn_root)) continue;
-                // shift the origin to (just before) the entry point, so that its fp32 rounding error inside the
-                // traversal (2^-24 of the mesh size) is far inside the 2^-18 inflation of the boxes
-                t_enter = tn_root > 0 ? tn_root * 0.99999905f : 0.0f;
-                const double te = (double)t_enter;
-                const float sx = (float)((r.o.x + te * r.d.x) - me.center[0]);
-                const float sy = (float)((r.o.y + te * r.d.y) - me.center[1]);
-                const float sz = (float)((r.o.z + te * r.d.z) - me.center[2]);
-                t_ax = ix; t_ay = iy; t_az = iz;
-                t_bx = -sx * ix; t_by = -sy * iy; t_bz = -sz * iz;
-                limf = f32_up(lim - te);
-                t_obj = me.obj;
-                t_cur = me.froot;
-            }
+        for (int m = 0; m < sc.n_meshes; m++) {  // wave-uniform
+            const auto &me = as_const(sc.meshes)[m];
+            if (me.froot == FNODE_NONE) continue;
+            // a shadow query skips Emmit objects and stops at its first occluder
+            const bool want = armed && !(shadow && (occ || !me.occluder));
+            if (__ballot(want) == 0ull) continue;
+            const double lim = shadow ? light_dist : bt;
+            // root cull in mesh-centred fp32.  The origin may be far from the mesh, so its rounding error
+            // (2^-24 of its distance) is added to the box as an explicit margin.
+            const float cxo = (float)(r.o.x - me.center[0]), cyo = (float)(r.o.y - me.center[1]), czo = (float)(r.o.z - me.center[2]);
+            const float mg = 4.76837158e-7f * fmaxf(fmaxf(fabsf(cxo), fabsf(cyo)), fabsf(czo));  // 2^-21 * max |o - c|
+            float lo[3] = {me.flo[0] - mg, me.flo[1] - mg, me.flo[2] - mg};
+            float hi[3] = {me.fhi[0] + mg, me.fhi[1] + mg, me.fhi[2] + mg};
+            float tn_root;
+            if (COUNT && want) cnt.c[CNT_NODES]++;
+            const bool enter = fbox(lo, hi, cxo, cyo, czo, ix, iy, iz, f32_up(lim), tn_root) && want;
+            if (__ballot(enter) == 0ull) continue;
+            // shift the origin to (just before) the entry point, so that its fp32 rounding error inside the
+            // traversal (2^-24 of the mesh size) is far inside the 2^-18 inflation of the boxes
+            t_enter = tn_root > 0 ? tn_root * 0.99999905f : 0.0f;
+            const double te = (double)t_enter;
+            const float sx = (float)((r.o.x + te * r.d.x) - me.center[0]);
+            const float sy = (float)((r.o.y + te * r.d.y) - me.center[1]);
+            const float sz = (float)((r.o.z + te * r.d.z) - me.center[2]);
+            t_ax = ix; t_ay = iy; t_az = iz;
+            t_bx = -sx * ix; t_by = -sy * iy; t_bz = -sz * iz;
+            float limf = f32_up(lim - te);
+            const int obj = me.obj;
+            stop_traversal();
+            if (enter) t_cur = me.froot;
             TIME_ADD(12);
-            // phase 1: walk inner nodes until this lane holds a leaf (or runs out of nodes).  The body is
-            // branch-free apart from the stack push/pop: the whole 32-byte node is requested at once (one
-            // memory round trip per visit) and both child boxes are always tested.
-            while (t_cur != FNODE_NONE && t_pa == FNODE_NONE) {
-                LOOP_TICK(10);
+            while (true) {
+                // phase 1: walk inner nodes until this lane holds a leaf (or runs out of nodes).  The body is
+                // branch-free apart from the stack push/pop: the whole 64-byte node is requested at once (one
+                // memory round trip per visit) and both child boxes are always tested.
+                while (t_cur != FNODE_NONE && t_pa == FNODE_NONE) {
+                    LOOP_TICK(10);
 #ifdef RAYHS_PROFILE_LOOPS
-                if (COUNT) {  // coherence probe: how many active lanes sit on the same node as the first active lane
-                    const int leader = __builtin_amdgcn_readfirstlane(t_cur);
-                    if (t_cur == leader) cnt.c[14]++;
-                    if (__ballot(t_cur != leader) == 0ull && (int)__lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1) cnt.c[15]++;  // wave-uniform visits
-                }
+                    if (COUNT) {  // coherence probe: how many active lanes sit on the same node as the first active lane
+                        const int leader = __builtin_amdgcn_readfirstlane(t_cur);
+                        if (t_cur == leader) cnt.c[14]++;
+                        if (__ballot(t_cur != leader) == 0ull && (int)__lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1) cnt.c[15]++;  // wave-uniform visits
+                    }
 #endif
-                // Most visits are wave-uniform: the 64 lanes hold samples of the same few pixels and walk the upper tree
-                // together (55 % of the node-loop iterations on the dragon frame, 72 % at 4K / 64 spp).  Those fetch the
-                // node ONCE through the scalar cache into SGPRs; only diverged waves gather per lane.
-                const int lead = __builtin_amdgcn_readfirstlane(t_cur);
-                if (__ballot(t_cur != lead) == 0ull) visit(as_const(sc.fnodes)[lead], limf);
-                else visit(rec(sc.fnodes, t_cur), limf);
-            }
-            TIME_ADD(13);
-            // phase 2: the postponed leaf, with the reference's fp64 triangle test on the ORIGINAL ray
-            if (t_pa != FNODE_NONE) {
-                LOOP_TICK(12);
-                const int ref = ~t_pa;
-                const int first = ref >> 3, n = ref & 7;  // leaf references index the BVH-ordered arrays directly
-                for (int k = first; k < first + n; k++) {
-                    const DTri tr = rec(sc.ftris, k);
-                    if (COUNT) cnt.c[CNT_TRIS]++;
-                    double t, u, v;
-                    if (tri_test(tr, r, t, u, v)) {
-                        bool admitted = true;
-                        if (u < kEdgeBand || v < kEdgeBand || (u + v) > 1 - kEdgeBand)
-                            admitted = reference_path_admits(sc.nodes, rec(sc.fattrs, k).leaf_node, r.o, r.d);
-                        if (admitted) {
-                            if (shadow) occ = occ || in_front(r, t, point_light, light_d2);
-                            else if (offer(t, u, v, t_obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - (double)t_enter); }
+                    // Most visits are wave-uniform: the 64 lanes hold samples of the same few pixels and walk the upper tree
+                    // together (55 % of the node-loop iterations on the dragon frame, 72 % at 4K / 64 spp).  Those fetch the
+                    // node ONCE through the scalar cache into SGPRs; only diverged waves gather per lane.
+                    const int lead = __builtin_amdgcn_readfirstlane(t_cur);
+                    if (__ballot(t_cur != lead) == 0ull) visit(as_const(sc.fnodes)[lead], limf);
+                    else visit(rec(sc.fnodes, t_cur), limf);
+                }
+                TIME_ADD(13);
+                // phase 2: the postponed leaf, with the reference's fp64 triangle test on the ORIGINAL ray
+                if (t_pa != FNODE_NONE) {
+                    LOOP_TICK(12);
+                    const int ref = ~t_pa;
+                    const int first = ref >> 3, n = ref & 7;  // leaf references index the BVH-ordered arrays directly
+                    for (int k = first; k < first + n; k++) {
+                        const DTri tr = rec(sc.ftris, k);
+                        if (COUNT) cnt.c[CNT_TRIS]++;
+                        double t, u, v;
+                        if (tri_test(tr, r, t, u, v)) {
+                            bool admitted = true;
+                            if (u < kEdgeBand || v < kEdgeBand || (u + v) > 1 - kEdgeBand)
+                                admitted = reference_path_admits(sc.nodes, rec(sc.fattrs, k).leaf_node, r.o, r.d);
+                            if (admitted) {
+                                if (shadow) occ = occ || in_front(r, t, point_light, light_d2);
+                                else if (offer(t, u, v, obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - (double)t_enter); }
+                            }
                         }
                     }
+                    t_pa = t_pb;
+                    t_pb = FNODE_NONE;
+                    if (shadow && occ) stop_traversal();  // any occluder settles a shadow query
                 }
-                t_pa = t_pb;
-                t_pb = FNODE_NONE;
-                if (shadow && occ) stop_traversal();  // any occluder settles a shadow query
+                if (t_pa == FNODE_NONE && t_cur == FNODE_NONE && t_sp > 0) {
+                    t_sp--;
+                    t_cur = (int)stack[t_sp * TRACE_BLOCK];
+                }
+                TIME_ADD(14);
+                if (__ballot(traversing()) == 0ull) break;
             }
-            if (t_pa == FNODE_NONE && t_cur == FNODE_NONE && t_sp > 0) {
-                t_sp--;
-                t_cur = (int)stack[t_sp * TRACE_BLOCK];
-            }
-            TIME_ADD(14);
-            // leave when done, or when too few lanes traverse while others could work
-            const unsigned long long trav = __ballot(traversing());
-            if (trav == 0ull) break;
-            if (__popcll(trav) < RAYHS_SLICE_MIN && __ballot(!traversing() && useful_when_free) != 0ull) break;
         }
     }
 };
@@ -842,11 +834,9 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         // Straight-line sections (hit / shadow / exit -> lights -> specular -> return -> next sample)
         // keep the live ranges short; everything declared in this block dies before the query below.
         TIME_ADD(0);  // refill
-        // Lanes whose ray is still in flight keep their state; the others consume their answer.
-        const bool was_traversing = RAYHS_SLICE_MIN > 0 && tr.traversing();
-        if (!was_traversing) qkind = Q_NONE;
+        qkind = Q_NONE;
         occluded = tr.occ;
-        if (state != ST_DONE && !was_traversing) {
+        if (state != ST_DONE) {
             V3 result = mk(0, 0, 0);
             V3 c_p = mk(0, 0, 0), c_n = mk(0, 0, 0), c_cd = mk(0, 0, 0), c_A = mk(0, 0, 0);
             enum : int { A_NONE, A_LIGHT_NEXT, A_SPEC, A_RETURN, A_QUERY_READY };
@@ -860,10 +850,10 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                     const auto &ob = rec(sc.objects, tr.bobj);
                     if (COUNT) cnt.c[CNT_SHADED]++;
                     c_obj = tr.bobj;
-                    PARK_V(ray.d);
                     c_p = add(ray.o, scl(tr.bt, ray.d));  // rayAt (src/Geometry.hs:27-29)
                     double hu = 0, hv = 0;
                     const int mat_kind = ob.mat_kind;
+                    if (mat_kind == 0 || mat_kind == 2 || mat_kind == 4) PARK_V(ray.d);  // Mirror, Plastic, Transparent: the view direction is read again after the light loop
                     const bool need_uv = ((mat_kind == 1 || mat_kind == 2) && ob.cmap_kind != 0) || mat_kind == 6;
                     if (tr.btri >= 0) {
                         const DTriAttr &at = rec(tr.bref ? sc.attrs : sc.fattrs, tr.btri);
@@ -947,7 +937,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
             }
 
             TIME_ADD(1);  // hit / shadow / exit sections
-            if (step == A_LIGHT_NEXT) {
+            while (step == A_LIGHT_NEXT) {  // per lane; more than one pass only when a light's term is exactly zero
                 if (c_li < sc.n_lights) {
                     // lightAt (src/Light.hs:12-17) + diffuse (src/Material.hs:31-33)
                     const auto &L = rec(sc.lights, c_li);
@@ -963,7 +953,17 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                         q_point = true; q_dist = d;
                     }
                     // the light's diffuse term, added after the shadow query if unoccluded
-                    PARK_TERM(scl(hs_max(dot(ld, c_n), 0) * kPiInv, mulv(c_cd, lc)));
+                    const V3 term = scl(hs_max(dot(ld, c_n), 0) * kPiInv, mulv(c_cd, lc));
+                    // A term of +-0 in every channel (the surface faces away from the light) leaves the running sum as it
+                    // is whether the light is occluded (c + black) or not (c + term): the sum starts at +0 and IEEE addition
+                    // of +-0 to anything but -0 is the identity.  The shadow query cannot matter and is not traced.  (The
+                    // exhaustive kernels trace it: their work counters are the reference's.)
+                    if (!EXH && term.x == 0 && term.y == 0 && term.z == 0) {
+                        if (COUNT) { cnt.c[CNT_SHADOW]++; cnt.c[CNT_SHADOW_SKIPPED]++; }
+                        c_li++;
+                        continue;
+                    }
+                    PARK_TERM(term);
                     ray.o = add(c_p, scl(kEps, ld)); ray.d = ld;  // rayEps p ld
                     if (q_point) { V3 dd = sub(ray.o, ld3(L.v)); q_d2 = dot(dd, dd); }  // sqrDist origin p (src/RayHs.hs:87)
                     if (COUNT) cnt.c[CNT_SHADOW]++;
@@ -1066,10 +1066,9 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         // parked values in LDS / the workspace instead of forwarding them through registers.
         asm volatile("" ::: "memory");
         TIME_ADD(10);
-        tr.begin(was_traversing ? Q_NONE : qkind, ray, q_point, q_d2);
+        tr.begin(qkind, ray, q_point, q_d2);
         TIME_ADD(11);
-        tr.slice(qkind == Q_SHADOW, ray, q_point, q_d2, q_dist, state != ST_DONE || !exhausted);
-        if (RAYHS_SLICE_MIN == 0) tr.forget_traversal();
+        tr.traverse(qkind == Q_SHADOW, ray, q_point, q_d2, q_dist);
         TIME_ADD(15);
         asm volatile("" ::: "memory");
     }

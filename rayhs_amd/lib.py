@@ -59,11 +59,13 @@ class Stats(C.Structure):
     """rayhs_stats."""
     _fields_ = [(n, C.c_uint64) for n in
                 ("rays_primary", "rays_reflect", "rays_refract", "rays_refract_exit", "rays_shadow",
-                 "nodes_tested", "tris_tested", "prims_tested", "shaded_hits", "pixels")] + [("kernel_ms", C.c_double)]
+                 "nodes_tested", "tris_tested", "prims_tested", "shaded_hits", "pixels")] + [("kernel_ms", C.c_double),
+                                                                                            ("shadow_skipped", C.c_uint64)]
 
     def as_dict(self):
         d = {n: (float(getattr(self, n)) if n == "kernel_ms" else int(getattr(self, n))) for n, _ in self._fields_}
-        d["rays"] = sum(v for k, v in d.items() if k.startswith("rays_"))
+        d["rays"] = sum(v for k, v in d.items() if k.startswith("rays_"))   # the reference's scene queries
+        d["rays_traced"] = d["rays"] - d["shadow_skipped"]                   # ... of which these were really traced
         return d
 
 

@@ -369,6 +369,22 @@ def test_headline_scene_band_against_oracle():
     r.close()
 
 
+SECOND = json.load(open(os.path.join(GOLD, "second.json")))
+
+
+@pytest.mark.parametrize("name", [n for n, m in SECOND.items() if m["rows"] is not None])
+def test_production_kernel_equals_the_second_restatement_on_baseline_windows(name):
+    # vectors of oracle/second/ (plain Python written from the Haskell alone; they did not come from the C oracle):
+    # pixel windows of configs[1]..[4] at their own size and sample count
+    m = SECOND[name]
+    want = np.load(os.path.join(GOLD, f"second_{name}.npy"))
+    r = build_rendering(m["scene"])
+    for i, y in enumerate(m["rows"]):
+        row, _ = r.ray_trace(spp=m["spp"], seed=m["seed"], row0=y, row1=y + 1)
+        assert np.array_equal(row[0][m["cols"]], want[i]), (name, y)
+    r.close()
+
+
 # ---------------------------------------- BASELINE configs: WHOLE frames, production kernels
 # tests/golden/frame_digests.json holds sha256 + exact per-row sums of the oracle's full frames of configs[1]..[4]
 # (tests/golden/make_frame_digests.py, run once in the build container: the 4K / 64 spp frame is 2.5 G rays).

@@ -29,7 +29,7 @@ def test_library_is_in_tree_and_exports_every_declared_symbol():
     lib = C.CDLL(L.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert L.load().rayhs_abi_version() == 1
+    assert L.load().rayhs_abi_version() == 2
 
 
 def test_header_is_plain_c_and_a_c_client_links(tmp_path):
@@ -44,14 +44,14 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
                          "-L", bindir, "-lrayhs_hip", "-Wl,-rpath," + bindir], capture_output=True, text=True)
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert run.returncode == 0 and run.stdout.split()[0] == "1"
+    assert run.returncode == 0 and run.stdout.split()[0] == "2"
 
 
 def test_struct_sizes_match_the_header():
     # layout guard for the ctypes mirrors (x86-64 SysV)
     assert C.sizeof(L.Camera) == 3 * 24 + 8 + 4 * 8
     assert C.sizeof(L.RenderParams) == 56
-    assert C.sizeof(L.Stats) == 11 * 8
+    assert C.sizeof(L.Stats) == 12 * 8
     assert C.sizeof(L.SceneDesc) == 328
 
 

@@ -45,7 +45,7 @@ def test_fresnel_schlick_and_power_chain():
     assert L.orc_fresnel(1.9, 1.0) == r                      # (1 - 1)^5 = 0
     assert L.orc_fresnel(1.9, 0.0) == r + (1 - r) * 1.0      # grazing: 1
     x = 1 - 0.3
-    assert L.orc_fresnel(1.9, 0.3) == r + (1 - r) * (((x * x) * (x * x)) * x)  # GHC (^): (x^2)^2 * x
+    assert L.orc_fresnel(1.9, 0.3) == r + (1 - r) * ((((x * x) * x) * x) * x)  # GHC -O: RULES "^5/Int" -> u*u*u*u*u
     assert L.orc_fresnel(1.9, -0.5) > 1.0                    # cos0 < 0 exceeds 1
 
 
@@ -362,3 +362,113 @@ def test_single_thread_equals_multi_thread_and_row_ranges():
     b, _ = O.render_file("scenes/cornell_96.json", nthreads=4)
     c, _ = O.render_file("scenes/cornell_96.json", row0=40, row1=50)
     assert np.array_equal(a, b) and np.array_equal(a[40:50], c)
+
+
+# ---- whole pixels derived by hand from the Haskell formulas (exact equality: same operations, same order)
+def _render_text(jd, **kw):
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump(jd, f)
+    try:
+        return O.render_file(f.name, **kw)[0]
+    finally:
+        os.unlink(f.name)
+
+
+def _camera_json(fovy=0.9272952180016123):
+    return {"position": {"x": 0, "y": 0, "z": -2}, "target": {"x": 0, "y": 0, "z": 0}, "up": {"x": 0, "y": 1, "z": 0},
+            "projection": {"type": "perspective", "fovy": fovy, "width": 2, "height": 2, "near": 0.1}}
+
+
+def test_centre_pixel_of_a_plastic_sphere_under_a_point_light_by_hand():
+    # 4x4 image: pixel (2, 2) has corner coordinates (w/2, h/2) -> view-plane position (0, 0, f) (Projection.hs:34-39).
+    # Sphere centre (0,0,1) r 0.5, plastic ior 1.5 flat (0.8,0.6,0.4); point light ON the camera axis at (0,0,-1);
+    # maxDepth 0, so specular is black and the pixel is  accumDiffuse + fresnel * black  (RayHs.hs:104,117-120).
+    w = h = 4.0
+    fovy = 0.9272952180016123
+    f = 0.5 * h / (math.tan(0.5) * fovy)
+    dz = (1 / math.sqrt(0.0 * 0.0 + 0.0 * 0.0 + f * f)) * f            # normalize (Vec 0 0 f); lookAt here is the identity
+    o = -2.0
+    a = 0.0 * 0.0 + 0.0 * 0.0 + dz * dz                                 # Geometry.hs:86-91
+    b = 2.0 * (0.0 * 0.0 + 0.0 * 0.0 + dz * (o - 1.0))
+    c = (0.0 + 0.0 + (o - 1.0) * (o - 1.0)) - 0.5 * 0.5
+    delta = b * b - 4.0 * a * c
+    t0 = 0.5 * ((-b) - math.sqrt(delta)) / a
+    assert t0 > 0
+    pz = o + t0 * dz                                                    # rayAt
+    nz = (1 / math.sqrt(0.0 + 0.0 + (pz - 1.0) * (pz - 1.0))) * (pz - 1.0)   # normalize (p0 - ct)
+    assert nz == -1.0
+    d = math.sqrt(0.0 + 0.0 + (-1.0 - pz) * (-1.0 - pz))                # Light.hs:15-17: dist p0 p
+    ldz = (1 / d) * (-1.0 - pz)
+    falloff = 1.0 / ((1.0 + d / 0.2) * (1.0 + d / 0.2))
+    lam = max(0.0 * 0.0 + 0.0 * 0.0 + ldz * nz, 0) * (1 / math.pi)      # Material.hs:31-33
+    cd, lc = (0.8, 0.6, 0.4), 30.0
+    r = ((1.0 - 1.5) / (1.0 + 1.5)) ** 2                                # r0 1.0 ior (u*u)
+    cos0 = 0.0 * -0.0 + 0.0 * -0.0 + nz * (-dz)                         # dot n (-v)
+    x = 1 - cos0
+    fres = r + (1 - r) * (x * x * x * x * x)
+    want = [(0.0 + lam * (k * (falloff * lc))) + fres * 0.0 for k in cd]
+    sph = {"geometry": {"type": "sphere", "center": {"x": 0, "y": 0, "z": 1}, "radius": 0.5},
+           "material": {"type": "plastic", "ior": 1.5, "cd": {"type": "flat", "color": {"r": 0.8, "g": 0.6, "b": 0.4}}}}
+    light = {"type": "point", "position": {"x": 0, "y": 0, "z": -1}, "color": {"r": 30, "g": 30, "b": 30}, "radius": 0.2}
+    img = _render_text({"width": 4, "height": 4, "maxDepth": 0, "camera": _camera_json(fovy), "scene": {"objects": [sph], "lights": [light]}})
+    assert list(img[2, 2]) == want and want[0] > 0.05
+
+
+def test_checker_cell_and_ambient_only_pixel_by_hand():
+    # a checker floor y = -1 (tangent x, so u = x, v = cross t n . rel = -z... evaluated below) seen by pixel (1, 3) of a
+    # 4x4 image, no lights: the pixel is 0.2 * colorAt (RayHs.hs:111-114), and colorAt picks color1 iff
+    # (mod' u s - 0.5 s) * (mod' v s - 0.5 s) < 0 (ColorMap.hs:21-24)
+    from fractions import Fraction
+    w = h = 4.0
+    fovy = 0.9272952180016123
+    f = 0.5 * h / (math.tan(0.5) * fovy)
+    vx, vy = w * (1.0 - (w / 2)) / w, h * ((-3.0) + (h / 2)) / h        # aspect 1: apw = aspect*h = 4, aph = 4
+    inv = 1 / math.sqrt(vx * vx + vy * vy + f * f)
+    dx, dy, dz = inv * vx, inv * vy, inv * f
+    ddn = dx * 0.0 + dy * 1.0 + dz * 0.0                                # Geometry.hs:70-79, n = (0,1,0), p = (0,-1,0)
+    time = (0.0 * (0.0 - 0.0) + 1.0 * (-1.0 - 0.0) + 0.0 * (0.0 - -2.0)) / ddn
+    assert abs(ddn) > 0 and time > 0
+    px, py, pz = 0.0 + time * dx, 0.0 + time * dy, -2.0 + time * dz
+    relx, rely, relz = px - 0.0, py - -1.0, pz - 0.0
+    t = (1.0, 0.0, 0.0)
+    bvec = (t[1] * 0.0 - t[2] * 1.0, t[2] * 0.0 - t[0] * 0.0, t[0] * 1.0 - t[1] * 0.0)   # cross t n
+    u = t[0] * relx + t[1] * rely + t[2] * relz
+    v = bvec[0] * relx + bvec[1] * rely + bvec[2] * relz
+    s = 0.3
+
+    def mod_prime(n, d):
+        return n - float(math.floor(Fraction(n) / Fraction(d))) * d
+    first = (mod_prime(u, s) - (0.5 * s)) * (mod_prime(v, s) - (0.5 * s)) < 0
+    c1, c2 = (1.0, 0.25, 0.5), (0.125, 2.0, 0.75)
+    want = [0.2 * k for k in (c1 if first else c2)]
+    floor = {"geometry": {"type": "plane", "point": {"x": 0, "y": -1, "z": 0}, "normal": {"x": 0, "y": 1, "z": 0}, "tangent": {"x": 1, "y": 0, "z": 0}},
+             "material": {"type": "diffuse", "cd": {"type": "checker", "color1": dict(zip("rgb", c1)), "color2": dict(zip("rgb", c2)), "size": s}}}
+    img = _render_text({"width": 4, "height": 4, "maxDepth": 3, "camera": _camera_json(fovy), "scene": {"objects": [floor], "lights": []}})
+    assert list(img[3, 1]) == want
+    # and the neighbouring cell along u flips the colour
+    other = [0.2 * k for k in (c2 if first else c1)]
+    row = _render_text({"width": 64, "height": 64, "maxDepth": 3, "camera": _camera_json(fovy), "scene": {"objects": [floor], "lights": []}})[60]
+    assert any(list(p) == want for p in row) and any(list(p) == other for p in row)
+
+
+# ---- the second, independent restatement (oracle/second/, plain Python written from the Haskell alone)
+SECOND = json.load(open(os.path.join(GOLD, "second.json")))
+
+
+@pytest.mark.parametrize("name", [n for n, m in SECOND.items() if m["rows"] is not None])
+def test_oracle_equals_the_second_restatement_on_windows_of_the_baseline_frames(name):
+    # fixtures written by oracle/second/check_second.py: they did NOT come from the C oracle
+    m = SECOND[name]
+    want = np.load(os.path.join(GOLD, f"second_{name}.npy"))
+    for i, y in enumerate(m["rows"]):
+        row, _ = O.render_file(m["scene"], width=m["width"], height=m["height"], spp=m["spp"], seed=m["seed"], row0=y, row1=y + 1)
+        assert np.array_equal(row[0][m["cols"]], want[i]), (name, y)
+
+
+def test_second_restatement_agrees_live_on_a_small_frame():
+    # the Python restatement itself, run here (seconds): a 24x24 frame of the dragon scene with every kind of ray
+    from oracle.second import rayhs_second as S
+    rows = S.render_file("scenes/dragon_superlow_96.json", width=24, height=24, spp=2, seed=24)
+    first, _ = O.render_file("scenes/dragon_superlow_96.json", width=24, height=24, spp=2, seed=24)
+    assert np.array_equal(np.array(rows), first)
