@@ -68,12 +68,34 @@ namespace rayhs {
 struct V3 { double x, y, z; };
 #define DEV static __device__ __forceinline__
 
+// Everything the kernel is given.  It is passed BY VALUE as the one kernel parameter and never touched through that
+// parameter: the code reads it from the kernarg segment (constant address space -> scalar loads) at the point of use,
+// through a pointer that is laundered at every mention so that the compiler cannot hoist those loads to the top of the
+// kernel.  Preloaded up front, the ~110 dwords of scene pointers, camera and launch parameters would have to live in
+// SGPRs across the whole main loop; gfx950 has 102 of them, and the overflow is spilled into VGPR lanes and read
+// back with v_readlane (a VALU instruction) at every use -- a quarter of the kernel's static VALU count before this.
+struct KArgs {
+    DScene sc;
+    DCamera cam;
+    DParams prm;
+    void *out;
+    unsigned long long *counters, *ticket;
+    double *frames;
+};
+
 // Scene tables (planes, spheres, meshes, objects, lights) are read through the constant address
 // space: a wave-uniform index then becomes a scalar load into SGPRs instead of 64 identical
 // per-lane loads into VGPRs.  LDS columns are addressed through explicit local-address-space
 // pointers so that they compile to ds_read/ds_write rather than flat accesses.
 template <class T> using cptr = const T __attribute__((address_space(4))) *;
 template <class T> static __device__ __forceinline__ cptr<T> as_const(const T *p) { return (cptr<T>)(unsigned long long)p; }
+static __device__ __forceinline__ cptr<KArgs> kargs() {
+    cptr<KArgs> p = (cptr<KArgs>)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#define SC (kargs()->sc)
+#define PRM (kargs()->prm)
 typedef double __attribute__((address_space(3))) *lds_dptr;
 
 DEV V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -215,7 +237,7 @@ static __device__ __attribute__((noinline)) bool reference_path_admits(const DNo
 constexpr double kEdgeBand = 1e-6;  // barycentric distance from an edge below which the path is replayed
 
 // rayFromPixel (src/Projection.hs:22-39); camera constants precomputed on the host
-DEV Ray ray_from_pixel(const DCamera &c, double px, double py) {
+template <class CAM> DEV Ray ray_from_pixel(const CAM &c, double px, double py) {
     double vx = c.apw * (px - c.half_w) / c.w;
     double vy = c.aph * ((-py) + c.half_h) / c.h;
     V3 o, d;
@@ -271,7 +293,6 @@ template <typename T> DEV const T &rec(const T *base, int index) {
 template <bool EXH, bool COUNT, typename StackT>
 struct Tracer {
     typedef StackT __attribute__((address_space(3))) *stack_ptr;
-    const DScene &sc;
     stack_ptr stack;  // this lane's LDS column: stack[level * TRACE_BLOCK]
     Counters &cnt;
 
@@ -293,7 +314,7 @@ struct Tracer {
     __device__ __forceinline__ bool traversing() const { return t_cur != FNODE_NONE || t_pa != FNODE_NONE || t_sp > 0; }
     __device__ __forceinline__ void stop_traversal() { t_cur = FNODE_NONE; t_pa = FNODE_NONE; t_pb = FNODE_NONE; t_sp = 0; }
 
-    __device__ Tracer(const DScene &s, stack_ptr st, Counters &c) : sc(s), stack(st), cnt(c) {
+    __device__ Tracer(stack_ptr st, Counters &c) : stack(st), cnt(c) {
         bt = 0; bu = 0; bv = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; occ = false; armed = false;
         t_ax = t_ay = t_az = t_bx = t_by = t_bz = t_enter = 0;
         stop_traversal();
@@ -421,8 +442,10 @@ struct Tracer {
         const double a = dot(r.d, r.d);
         const double o_max = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z));
         const double o_guard = (o_max * o_max) * 1e-18;
-        for (int i = 0; i < sc.n_planes && wave_active != 0ull; i++) {
-            const auto &pl = as_const(sc.planes)[i];
+        const int n_planes = SC.n_planes, n_spheres = SC.n_spheres, n_meshes = SC.n_meshes;
+        const auto planes = as_const(SC.planes);
+        for (int i = 0; i < n_planes && wave_active != 0ull; i++) {
+            const auto &pl = planes[i];
             // outside the exhaustive kernels a shadow query skips Emmit objects and stops at its first occluder
             const bool consider = active && (EXH || !(shadow && (occluded || !pl.occluder)));
             if (__ballot(consider) == 0ull) continue;
@@ -447,8 +470,9 @@ struct Tracer {
             const bool better = hit && !shadow && (t < bt || (t == bt && pl.obj < bobj));
             bt = better ? t : bt; bobj = better ? pl.obj : bobj; bprim = better ? i : bprim;
         }
-        for (int i = 0; i < sc.n_spheres && wave_active != 0ull; i++) {
-            const auto &s = as_const(sc.spheres)[i];
+        const auto spheres = as_const(SC.spheres);
+        for (int i = 0; i < n_spheres && wave_active != 0ull; i++) {
+            const auto &s = spheres[i];
             const bool consider = active && (EXH || !(shadow && (occluded || !s.occluder)));
             if (__ballot(consider) == 0ull) continue;
             if (COUNT && consider) cnt.c[CNT_PRIMS]++;
@@ -463,7 +487,7 @@ struct Tracer {
             const bool better = hit && !shadow && (t < bt || (t == bt && s.obj < bobj));
             bt = better ? t : bt; bobj = better ? s.obj : bobj; bprim = better ? -(i + 2) : bprim;
         }
-        if (sc.n_meshes > 0) {
+        if (n_meshes > 0) {
             // The reference's slab test multiplies by 1/d: with a zero direction component and a box plane
             // through the origin it computes 0 * inf = NaN and may reject a box the ray does touch
             // (src/KDTree.hs:39-56).  Its boxes are therefore NOT a conservative cull for such rays, and only
@@ -480,8 +504,12 @@ struct Tracer {
     // ---- the reference's own tree, both children always (src/KDTree.hs:96-115)
     __device__ __forceinline__ bool meshes_reference(bool active, bool shadow, const Ray &r, bool point_light, double light_d2, bool occluded) {
         const V3 inv = mk(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);  // src/KDTree.hs:46-48
-        for (int m = 0; m < sc.n_meshes; m++) {
-            const auto &me = as_const(sc.meshes)[m];
+        const int n_meshes = SC.n_meshes;
+        const auto meshes = as_const(SC.meshes);
+        const DNode *const nodes = SC.nodes;
+        const DTri *const tris = SC.tris;
+        for (int m = 0; m < n_meshes; m++) {
+            const auto &me = meshes[m];
             // outside the exhaustive kernels a shadow query may stop at its first occluder and skip Emmit objects
             int node = active && (EXH || !(shadow && (occluded || !me.occluder))) ? me.root : -1;
             int sp = 0;
@@ -492,7 +520,7 @@ struct Tracer {
                     node = (int)stack[sp * TRACE_BLOCK];
                     continue;
                 }
-                const DNode nd = rec(sc.nodes, node);
+                const DNode nd = rec(nodes, node);
                 if (COUNT) cnt.c[CNT_NODES]++;
                 double tmin;
                 int next = -1;
@@ -500,7 +528,7 @@ struct Tracer {
                     if (nd.flags & DNODE_LEAF) {
                         const int first = nd.a, last = nd.a + nd.b;
                         for (int k = first; k < last; k++) {
-                            const DTri tr = rec(sc.tris, k);
+                            const DTri tr = rec(tris, k);
                             if (COUNT) cnt.c[CNT_TRIS]++;
                             double t, u, v;
                             if (tri_test(tr, r, t, u, v)) {
@@ -559,8 +587,12 @@ struct Tracer {
         // reciprocal direction in fp32 (1 ulp): every use below is a conservative cull, never a result
         const float ix = __builtin_amdgcn_rcpf((float)r.d.x), iy = __builtin_amdgcn_rcpf((float)r.d.y), iz = __builtin_amdgcn_rcpf((float)r.d.z);
         TIME_DECL;
-        for (int m = 0; m < sc.n_meshes; m++) {  // wave-uniform
-            const auto &me = as_const(sc.meshes)[m];
+        const int n_meshes = SC.n_meshes;
+        const auto meshes = as_const(SC.meshes);
+        const FNode *const fnodes = SC.fnodes;
+        const DTri *const ftris = SC.ftris;
+        for (int m = 0; m < n_meshes; m++) {  // wave-uniform
+            const auto &me = meshes[m];
             if (me.froot == FNODE_NONE) continue;
             // a shadow query skips Emmit objects and stops at its first occluder
             const bool want = armed && !(shadow && (occ || !me.occluder));
@@ -607,8 +639,8 @@ struct Tracer {
                     // together (55 % of the node-loop iterations on the dragon frame, 72 % at 4K / 64 spp).  Those fetch the
                     // node ONCE through the scalar cache into SGPRs; only diverged waves gather per lane.
                     const int lead = __builtin_amdgcn_readfirstlane(t_cur);
-                    if (__ballot(t_cur != lead) == 0ull) visit(as_const(sc.fnodes)[lead], limf);
-                    else visit(rec(sc.fnodes, t_cur), limf);
+                    if (__ballot(t_cur != lead) == 0ull) visit(as_const(fnodes)[lead], limf);
+                    else visit(rec(fnodes, t_cur), limf);
                 }
                 TIME_ADD(13);
                 // phase 2: the postponed leaf, with the reference's fp64 triangle test on the ORIGINAL ray
@@ -617,13 +649,13 @@ struct Tracer {
                     const int ref = ~t_pa;
                     const int first = ref >> 3, n = ref & 7;  // leaf references index the BVH-ordered arrays directly
                     for (int k = first; k < first + n; k++) {
-                        const DTri tr = rec(sc.ftris, k);
+                        const DTri tr = rec(ftris, k);
                         if (COUNT) cnt.c[CNT_TRIS]++;
                         double t, u, v;
                         if (tri_test(tr, r, t, u, v)) {
                             bool admitted = true;
                             if (u < kEdgeBand || v < kEdgeBand || (u + v) > 1 - kEdgeBand)
-                                admitted = reference_path_admits(sc.nodes, rec(sc.fattrs, k).leaf_node, r.o, r.d);
+                                admitted = reference_path_admits(SC.nodes, rec(SC.fattrs, k).leaf_node, r.o, r.d);
                             if (admitted) {
                                 if (shadow) occ = occ || in_front(r, t, point_light, light_d2);
                                 else if (offer(t, u, v, obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - (double)t_enter); }
@@ -673,8 +705,7 @@ DEV V3 cx_load3(lds_dptr cx, int slot) { return mk(cx[slot * TRACE_BLOCK], cx[(s
 #define LOAD_TERM() (term_in_lds ? cx_load3(cx, CX_TERM) : ws_load3(ws, LS_TERM))
 
 template <bool EXH, bool COUNT, typename StackT>
-static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DParams &prm, void *out,
-                                  unsigned long long *counters, unsigned long long *ticket, double *frames) {
+static __device__ void trace_body() {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -683,11 +714,11 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     for (int i = 0; i < 16; i++) cnt.c[i] = 0;
     lds_dptr cx = (lds_dptr)lds + tid;                                                  // context column
     typedef StackT __attribute__((address_space(3))) *stack_ptr;
-    stack_ptr stk = (stack_ptr)((lds_dptr)lds + prm.ctx_slots * TRACE_BLOCK) + tid;      // stack column
-    const bool term_in_lds = prm.ctx_slots >= 15;  // wave-uniform: the launcher grants 3 more slots when LDS has room
-    Tracer<EXH, COUNT, StackT> tr(sc, stk, cnt);
-    const Workspace ws = {frames, (unsigned)prm.frame_stride, (unsigned)gtid};
-    const uint64_t seed_mixed = mix64(prm.seed + 0x9e3779b97f4a7c15ULL);
+    const int ctx_slots = PRM.ctx_slots;
+    stack_ptr stk = (stack_ptr)((lds_dptr)lds + ctx_slots * TRACE_BLOCK) + tid;          // stack column
+    const bool term_in_lds = ctx_slots >= 15;  // wave-uniform: the launcher grants 3 more slots when LDS has room
+    Tracer<EXH, COUNT, StackT> tr(stk, cnt);
+    const Workspace ws = {kargs()->frames, (unsigned)PRM.frame_stride, (unsigned)gtid};
 
     // per-lane state that stays in registers across a scene query
     int state = ST_DONE;
@@ -705,7 +736,6 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     // sample gets the next one at once.  (Per-pixel items left the frame waiting on single lanes that
     // held an expensive pixel: 16 samples in sequence.)
     constexpr unsigned kChunk = RAYHS_CHUNK;
-    const unsigned long long total_items = (unsigned long long)prm.n_tiles * 64ull * (unsigned long long)prm.spp;
     unsigned long long pool_next = 0, pool_end = 0;
     bool exhausted = false;
     // XCD-aware work distribution: the item space is cut into 8 contiguous ranges (bands of tiles), each with
@@ -713,7 +743,6 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     // (HW_REG_XCC_ID), so one XCD's L2 mostly sees one part of the frame and of the BVH; when its range is
     // used up it moves on to the next one, so the split only steers locality, never the balance.
     constexpr int kRanges = 8;
-    const unsigned long long per_range = ((total_items + (unsigned long long)kRanges * kChunk - 1) / ((unsigned long long)kRanges * kChunk)) * kChunk;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
     int range = (int)(xcc & (kRanges - 1)), ranges_done = 0;
@@ -725,7 +754,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     unsigned long long chunk_t0 = 0;  // when the current chunk was obtained, and the tile it belongs to (a chunk never straddles tiles)
     int chunk_tile = 0;
     unsigned long long ticket_ahead = 0;  // lane 0: ticket of `range` requested ahead of need
-    if (lane == 0) ticket_ahead = atomicAdd(ticket + range * 8, (unsigned long long)kChunk);
+    if (lane == 0) ticket_ahead = atomicAdd(kargs()->ticket + range * 8, (unsigned long long)kChunk);
 
     TIME_DECL;
 #ifdef RAYHS_PROFILE_TIME
@@ -734,6 +763,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
     while (true) {
         unsigned long long idle = __ballot(state == ST_DONE);
         if (chunk_pending && idle == ~0ull) {  // the chunk this wave held is finished
+            const auto &prm = kargs()->prm;
             if (prm.wave_resolve && item_valid && sample == 0) {
                 V3 sum = mk(0, 0, 0);
                 auto at = [&](int k) { return mk(cx[CX_A * TRACE_BLOCK + k], cx[(CX_A + 1) * TRACE_BLOCK + k], cx[(CX_A + 2) * TRACE_BLOCK + k]); };
@@ -743,7 +773,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                     sum = add(add(add(add(sum, a), b), c), d);
                 }
                 for (; k < prm.spp; k++) sum = add(sum, at(k));
-                store_pixel(out, prm.out_format, (size_t)lrow * (size_t)prm.width + (size_t)px, scl(1.0 / (double)prm.spp, sum));
+                store_pixel(kargs()->out, prm.out_format, (size_t)lrow * (size_t)prm.width + (size_t)px, scl(1.0 / (double)prm.spp, sum));
             }
             // how long the chunk took, for the next frame's work order (costs are >= 0: their bit patterns order like the values)
             if (prm.tile_cost != nullptr && lane == 0)
@@ -753,7 +783,11 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
         }
         if (__popcll(idle) < RAYHS_REFILL_MIN) idle = 0ull;
         while (idle != 0ull && !exhausted) {  // wave-uniform
+            const auto &prm = kargs()->prm;
             if (pool_next == pool_end) {
+                unsigned long long *const ticket = kargs()->ticket;
+                const unsigned long long total_items = (unsigned long long)prm.n_tiles * 64ull * (unsigned long long)prm.spp;
+                const unsigned long long per_range = ((total_items + (unsigned long long)kRanges * kChunk - 1) / ((unsigned long long)kRanges * kChunk)) * kChunk;
                 // the ticket for this chunk was requested one refill ago; the next one is requested below, so that
                 // the atomic's round trip (microseconds) runs beside the chunk's work instead of in front of it
                 unsigned long long c = ticket_ahead;
@@ -847,7 +881,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                 // traceRay (src/RayHs.hs:149-154)
                 if (tr.bobj < 0) { result = mk(0, 0, 0); step = A_RETURN; }
                 else {
-                    const auto &ob = rec(sc.objects, tr.bobj);
+                    const auto &ob = rec(SC.objects, tr.bobj);
                     if (COUNT) cnt.c[CNT_SHADED]++;
                     c_obj = tr.bobj;
                     c_p = add(ray.o, scl(tr.bt, ray.d));  // rayAt (src/Geometry.hs:27-29)
@@ -856,7 +890,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                     if (mat_kind == 0 || mat_kind == 2 || mat_kind == 4) PARK_V(ray.d);  // Mirror, Plastic, Transparent: the view direction is read again after the light loop
                     const bool need_uv = ((mat_kind == 1 || mat_kind == 2) && ob.cmap_kind != 0) || mat_kind == 6;
                     if (tr.btri >= 0) {
-                        const DTriAttr &at = rec(tr.bref ? sc.attrs : sc.fattrs, tr.btri);
+                        const DTriAttr &at = rec(tr.bref ? SC.attrs : SC.fattrs, tr.btri);
                         double u = tr.bu, v = tr.bv, w = 1 - u - v;
                         // barycentricInterp u n1 v n2 (1-u-v) n0 (src/Mesh.hs:53-57,73-74)
                         c_n = add(add(scl(u, ld3(at.n1)), scl(v, ld3(at.n2))), scl(w, ld3(at.n0)));
@@ -865,17 +899,17 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                             hv = u * at.uv1[1] + v * at.uv2[1] + w * at.uv0[1];
                         }
                     } else if (tr.bprim >= 0) {  // re-derive the analytic hit from t
-                        const auto &pl = rec(sc.planes, tr.bprim);
+                        const auto &pl = rec(SC.planes, tr.bprim);
                         c_n = ld3(pl.n);
                         if (need_uv) { V3 rel = sub(c_p, ld3(pl.p)); hu = dot(ld3(pl.t), rel); hv = dot(ld3(pl.b), rel); }
                     } else {
-                        const auto &s = rec(sc.spheres, -tr.bprim - 2);
+                        const auto &s = rec(SC.spheres, -tr.bprim - 2);
                         c_n = unit(sub(c_p, ld3(s.c)));
                         if (need_uv) polar_uv(c_n, hu, hv);  // src/Geometry.hs:96
                     }
                     // irradiance (src/RayHs.hs:107-147)
                     if (mat_kind == 1 || mat_kind == 2) {  // Diffuse, Plastic
-                        c_cd = ob.cmap_kind == 0 ? ld3(ob.c1) : color_at_slow(as_const(sc.objects), tr.bobj, sc.texels, hu, hv);
+                        c_cd = ob.cmap_kind == 0 ? ld3(ob.c1) : color_at_slow(as_const(SC.objects), tr.bobj, SC.texels, hu, hv);
                         c_A = mk(0, 0, 0); c_li = 0;
                         step = A_LIGHT_NEXT;
                     } else if (mat_kind == 0) {  // Mirror
@@ -884,7 +918,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                         result = ld3(ob.ce); step = A_RETURN;
                     } else if (mat_kind == 4) {  // Transparent: try to transmit (src/RayHs.hs:136-143)
                         V3 refdir;
-                        if (depth != prm.max_depth && refract(ray.d, c_n, 1.0, ob.ior, refdir)) {
+                        if (depth != PRM.max_depth && refract(ray.d, c_n, 1.0, ob.ior, refdir)) {
                             c_cd = refdir;  // keep refDir across the exit query
                             ray.o = add(c_p, scl(kEps, refdir)); ray.d = refdir;  // rayEps
                             if (COUNT) cnt.c[CNT_REFRACT_EXIT]++;
@@ -902,17 +936,17 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
             } else if (state == ST_EXIT) {
                 // the transmitted ray's exit point (src/RayHs.hs:140-143)
                 c_p = cx_load3(cx, CX_P); c_n = cx_load3(cx, CX_N); c_cd = cx_load3(cx, CX_CD);
-                const auto &ob = rec(sc.objects, c_obj);
+                const auto &ob = rec(SC.objects, c_obj);
                 bool have = false;
                 if (tr.bobj >= 0) {
                     V3 outp = add(ray.o, scl(tr.bt, ray.d));
                     V3 outn;
                     if (tr.btri >= 0) {
-                        const DTriAttr &at = rec(tr.bref ? sc.attrs : sc.fattrs, tr.btri);
+                        const DTriAttr &at = rec(tr.bref ? SC.attrs : SC.fattrs, tr.btri);
                         double u = tr.bu, v = tr.bv, w = 1 - u - v;
                         outn = add(add(scl(u, ld3(at.n1)), scl(v, ld3(at.n2))), scl(w, ld3(at.n0)));
-                    } else if (tr.bprim >= 0) outn = ld3(rec(sc.planes, tr.bprim).n);
-                    else outn = unit(sub(outp, ld3(rec(sc.spheres, -tr.bprim - 2).c)));
+                    } else if (tr.bprim >= 0) outn = ld3(rec(SC.planes, tr.bprim).n);
+                    else outn = unit(sub(outp, ld3(rec(SC.spheres, -tr.bprim - 2).c)));
                     V3 outdir;
                     if (refract(c_cd, neg(outn), ob.ior, 1.0, outdir)) {
                         have = true;
@@ -938,9 +972,9 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
 
             TIME_ADD(1);  // hit / shadow / exit sections
             while (step == A_LIGHT_NEXT) {  // per lane; more than one pass only when a light's term is exactly zero
-                if (c_li < sc.n_lights) {
+                if (c_li < SC.n_lights) {
                     // lightAt (src/Light.hs:12-17) + diffuse (src/Material.hs:31-33)
-                    const auto &L = rec(sc.lights, c_li);
+                    const auto &L = rec(SC.lights, c_li);
                     V3 ld, lc;
                     if (L.kind == 0) { ld = ld3(L.v); lc = ld3(L.c); q_point = false; q_d2 = 0; q_dist = __builtin_inf(); }
                     else {
@@ -970,7 +1004,7 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
                     // park the context of the hit being shaded while its shadow ray is traced
                     cx_store3(cx, CX_P, c_p); cx_store3(cx, CX_N, c_n); cx_store3(cx, CX_CD, c_cd); cx_store3(cx, CX_A, c_A);
                     qkind = Q_SHADOW; state = ST_SHADOW; step = A_QUERY_READY;
-                } else if (rec(sc.objects, c_obj).mat_kind == 1) {
+                } else if (rec(SC.objects, c_obj).mat_kind == 1) {
                     result = add(scl(0.2, c_cd), c_A);  // Diffuse (src/RayHs.hs:111-114)
                     step = A_RETURN;
                 } else { spec_with_A = true; step = A_SPEC; }  // Plastic (src/RayHs.hs:117-120)
@@ -982,10 +1016,10 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
             TIME_ADD(2);  // light section
             if (step == A_SPEC) {
                 // fresnel * specular (src/RayHs.hs:99-104,119,124,132)
-                const auto &ob = rec(sc.objects, c_obj);
+                const auto &ob = rec(SC.objects, c_obj);
                 V3 c_v = LOAD_V();
                 double F = fresnel(ob.fr, dot(c_n, neg(c_v)));
-                if (depth < prm.max_depth) {
+                if (depth < PRM.max_depth) {
                     V3 rf = reflect(c_v, c_n);
                     ws_store(ws, fslot(fsp, FS_KIND), (double)(spec_with_A ? FR_PLASTIC : FR_MIRROR));
                     ws_store(ws, fslot(fsp, FS_DEPTH), (double)depth);
@@ -1008,15 +1042,15 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
             // hand `result` to the suspended callers until one needs another ray, or the sample is done
             while (step == A_RETURN) {
                 if (fsp == 0) {
-                    const size_t pix = (size_t)lrow * (size_t)prm.width + (size_t)px;
-                    if (prm.wave_resolve) {
+                    const size_t pix = (size_t)lrow * (size_t)PRM.width + (size_t)px;
+                    if (PRM.wave_resolve) {
                         cx_store3(cx, CX_A, result);  // waits in LDS for the in-wave resolve (the A slot is free now)
-                    } else if (prm.spp > 1) {
+                    } else if (PRM.spp > 1) {
                         // one sample of distributedTracePixel (src/RayHs.hs:173-183); rayhs_resolve folds them in order
-                        double *sb = prm.sbuf + (pix * (size_t)prm.spp + (size_t)sample) * 3;
+                        double *sb = PRM.sbuf + (pix * (size_t)PRM.spp + (size_t)sample) * 3;
                         sb[0] = result.x; sb[1] = result.y; sb[2] = result.z;
                     } else {
-                        store_pixel(out, prm.out_format, pix, result);
+                        store_pixel(kargs()->out, PRM.out_format, pix, result);
                     }
                     if (COUNT) cnt.c[CNT_PIXELS]++;
                     state = ST_DONE;
@@ -1050,12 +1084,14 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
             if (state == ST_NEW_SAMPLE) {
                 // pixelCoord (src/Image.hs:31-32) + optional sample offset (src/RayHs.hs:178-188)
                 double fx = (double)px, fy = (double)yrow;
+                const auto &prm = kargs()->prm;
                 if (prm.spp > 1) {
+                    const uint64_t seed_mixed = mix64(prm.seed + 0x9e3779b97f4a7c15ULL);
                     uint64_t pixel = (uint64_t)px + (uint64_t)prm.width * (uint64_t)yrow;
                     fx = fx + (sample01(seed_mixed, pixel, (uint32_t)sample, 0, (uint32_t)prm.spp) - 0.5);
                     fy = fy + (sample01(seed_mixed, pixel, (uint32_t)sample, 1, (uint32_t)prm.spp) - 0.5);
                 }
-                ray = ray_from_pixel(cam, fx, fy);
+                ray = ray_from_pixel(kargs()->cam, fx, fy);
                 depth = 0; fsp = 0;
                 if (COUNT) cnt.c[CNT_PRIMARY]++;
                 qkind = Q_CLOSEST; state = ST_HIT;
@@ -1075,12 +1111,16 @@ static __device__ void trace_body(const DScene &sc, const DCamera &cam, const DP
 
 #ifdef RAYHS_PROFILE_TIME
     cnt.c[8] = __builtin_amdgcn_s_memrealtime() - rt0_;  // 100 MHz ticks over the wave's life
+    unsigned long long *const counters = kargs()->counters;
     if (lane == 0 && counters != nullptr) {  // earliest start / latest end over all waves (slots 4, 5 are unused by the profile build)
         atomicMax(&counters[4], ~rt0_);
         atomicMax(&counters[5], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
     cnt.c[9] = __builtin_amdgcn_s_memrealtime();           // summed over waves: (latest end - mean end) is the idle tail
     (void)mt0_;
+#endif
+#ifndef RAYHS_PROFILE_TIME
+    unsigned long long *const counters = kargs()->counters;
 #endif
     if ((COUNT || kProfileTime) && counters != nullptr) {
         for (int i = 0; i < 16; i++) {
@@ -1102,9 +1142,8 @@ using namespace rayhs;
 #endif
 #define RAYHS_DEFINE_KERNEL(NAME, EXH, COUNT, STACKT, WPE)                                                        \
     extern "C" __global__ void __launch_bounds__(TRACE_BLOCK, WPE)                                                \
-    RAYHS_CAT(NAME, RAYHS_KERNEL_SUFFIX)(DScene sc, DCamera cam, DParams prm, void *out,                          \
-                                         unsigned long long *counters, unsigned long long *ticket, double *frames) {\
-        trace_body<EXH, COUNT, STACKT>(sc, cam, prm, out, counters, ticket, frames);                              \
+    RAYHS_CAT(NAME, RAYHS_KERNEL_SUFFIX)(KArgs never_read_through_this_parameter) {                                \
+        trace_body<EXH, COUNT, STACKT>();                                                                         \
     }
 
 // average (src/RayHs.hs:169-171): foldl (+) black over the samples in order, then mul (1 / n)
@@ -1189,7 +1228,9 @@ static const void *RAYHS_CAT(kernel_ptr, RAYHS_KERNEL_SUFFIX)(int variant) {
 hipError_t RAYHS_CAT(launch_trace, RAYHS_KERNEL_SUFFIX)(int variant, int grid, size_t lds_bytes, hipStream_t stream,
                                                         const DScene &sc, const DCamera &cam, const DParams &prm, void *out,
                                                         unsigned long long *counters, unsigned long long *ticket, double *frames) {
-    void *args[] = {(void *)&sc, (void *)&cam, (void *)&prm, (void *)&out, (void *)&counters, (void *)&ticket, (void *)&frames};
+    KArgs ka;
+    ka.sc = sc; ka.cam = cam; ka.prm = prm; ka.out = out; ka.counters = counters; ka.ticket = ticket; ka.frames = frames;
+    void *args[] = {(void *)&ka};
     return hipLaunchKernel(RAYHS_CAT(kernel_ptr, RAYHS_KERNEL_SUFFIX)(variant), dim3((unsigned)grid), dim3(TRACE_BLOCK), args, lds_bytes, stream);
 }
 hipError_t RAYHS_CAT(launch_resolve, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format) {
