@@ -22,6 +22,8 @@ hipError_t launch_trace_fast(int variant, int grid, size_t lds_bytes, hipStream_
 hipError_t launch_resolve_fast(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format);
 hipError_t launch_resolve_exact(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format);
 hipError_t launch_order_tiles_fast(hipStream_t stream, float *cost, int n, int *order);
+hipError_t launch_static_costs_fast(hipStream_t stream, const DScene &sc, const DCamera &cam, const DParams &prm, float *cost);
+hipError_t launch_static_costs_exact(hipStream_t stream, const DScene &sc, const DCamera &cam, const DParams &prm, float *cost);
 hipError_t launch_order_tiles_exact(hipStream_t stream, float *cost, int n, int *order);
 hipError_t launch_trace_exact(int variant, int grid, size_t lds_bytes, hipStream_t stream, const DScene &sc, const DCamera &cam,
                               const DParams &prm, void *out, unsigned long long *counters, unsigned long long *ticket, double *frames);
@@ -395,7 +397,7 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
     void *p = nullptr;
     if (hipMalloc(&p, sizeof(unsigned long long) * kTicketSlots * kTicketRings) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(tickets) failed"));
     s->tickets = (unsigned long long *)p;
-    if (hipMalloc(&p, sizeof(unsigned long long) * CNT_SLOTS) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(counters) failed"));
+    if (hipMalloc(&p, sizeof(unsigned long long) * CNT_SLOTS_DEV) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(counters) failed"));
     s->counters = (unsigned long long *)p;
     *out = s;
     return RAYHS_OK;
@@ -548,9 +550,10 @@ static int ensure_workspace(const rayhs_scene *s, const DParams &dp) {
 // long each of its chunks took (DParams.tile_cost) and, right behind it on the same stream, a one-workgroup kernel
 // turns those times into the tile order of the NEXT frame of the same geometry (size, rows, stripes, spp, depth) --
 // the same view in a progressive render or a benchmark, a neighbouring one in an animation.  The first frame of a
-// geometry runs in scan order.  Nothing is read back to the host.
-static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, int variant, DParams &dp, bool &record) {
-    dp.tile_order = nullptr; dp.tile_cost = nullptr; record = false;
+// geometry -- the only one a one-shot `rayhs -oX scene.json` renders -- is ordered by a static estimate instead
+// (rayhs_static_costs: mesh-box tiles first, reflective surfaces next).  Nothing is read back to the host.
+static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, int variant, DParams &dp, hipStream_t st, bool &record, bool &need_static) {
+    dp.tile_order = nullptr; dp.tile_cost = nullptr; record = false; need_static = false;
 #ifdef RAYHS_PROFILE_TIME
     const bool production = variant != 2;  // the diagnostic build's "counting" kernel is the production kernel with time stamps
 #else
@@ -571,10 +574,12 @@ static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, i
             s->cost_dev = (float *)q;
             s->order_cap = (size_t)dp.n_tiles;
         }
-        HIP_TRY(hipMemset(s->cost_dev, 0, (size_t)dp.n_tiles * sizeof(float)));  // once per geometry; afterwards the ordering kernel clears it
+        HIP_TRY(hipMemsetAsync(s->cost_dev, 0, (size_t)dp.n_tiles * sizeof(float), st));  // once per geometry, in stream order; afterwards the ordering kernel clears it
         std::memcpy(s->order_key, key, sizeof key);
     }
-    if (s->order_valid) dp.tile_order = s->order_dev;
+    // no measured order yet: the launcher runs the static estimate + ordering in front of the trace kernel
+    need_static = !s->order_valid && !std::getenv("RAYHS_NO_STATIC_ORDER");
+    if (s->order_valid || need_static) dp.tile_order = s->order_dev;
     dp.tile_cost = s->cost_dev;
     record = true;
     return RAYHS_OK;
@@ -598,16 +603,42 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
     if (!s->last_done) HIP_TRY(hipEventCreateWithFlags(&s->last_done, hipEventDisableTiming));
     if (s->have_last && s->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, s->last_done, 0));
     if ((rc = ensure_workspace(s, dp))) return rc;
-    bool record_costs = false;
-    if ((rc = plan_tile_order(s, p, variant, dp, record_costs))) return rc;
+    bool record_costs = false, static_order = false;
+    if ((rc = plan_tile_order(s, p, variant, dp, st, record_costs, static_order))) return rc;
     unsigned long long *ticket = s->tickets + (size_t)(s->next_ticket++ % kTicketRings) * kTicketSlots;
     HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long) * kTicketSlots, st));
     dp.sbuf = dp.spp > 1 && !dp.wave_resolve ? s->sbuf : nullptr;
+    if (static_order) {  // first frame of this geometry: static tile classes -> work order (two tiny kernels, ~20 us)
+        hipError_t es = exact ? launch_static_costs_exact(st, s->d, dc, dp, s->cost_dev) : launch_static_costs_fast(st, s->d, dc, dp, s->cost_dev);
+        if (es == hipSuccess) es = exact ? launch_order_tiles_exact(st, s->cost_dev, dp.n_tiles, s->order_dev) : launch_order_tiles_fast(st, s->cost_dev, dp.n_tiles, s->order_dev);
+        if (es != hipSuccess) return set_error(RAYHS_ERR_HIP, "static tile ordering launch failed: %s", hipGetErrorString(es));
+    }
     if (e0) HIP_TRY(hipEventRecord(e0, st));
     hipError_t e = exact ? launch_trace_exact(variant, grid, lds, st, s->d, dc, dp, d_out, (unsigned long long *)d_counters, ticket, s->frames)
                          : launch_trace_fast(variant, grid, lds, st, s->d, dc, dp, d_out, (unsigned long long *)d_counters, ticket, s->frames);
     if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "trace kernel launch failed: %s", hipGetErrorString(e));
     if (e1) HIP_TRY(hipEventRecord(e1, st));
+    if (record_costs && std::getenv("RAYHS_DUMP_TILE_COSTS")) {  // development: measured chunk times per tile, then the static estimate
+        std::vector<float> h((size_t)dp.n_tiles);
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(h.data(), s->cost_dev, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+        if (FILE *f = std::fopen(std::getenv("RAYHS_DUMP_TILE_COSTS"), "ab")) {
+            int hdr[4] = {dp.n_tiles, dp.tiles_x, dp.spp, 0};
+            std::fwrite(hdr, sizeof hdr, 1, f);
+            std::fwrite(h.data(), sizeof(float), h.size(), f);
+            void *tmp = nullptr;
+            HIP_TRY(hipMalloc(&tmp, h.size() * sizeof(float)));
+            DParams dpx = dp;
+            dpx.flags_dev = std::getenv("RAYHS_DUMP_RAW_FEATURE") ? 1 : 0;
+            hipError_t es = exact ? launch_static_costs_exact(st, s->d, dc, dpx, (float *)tmp) : launch_static_costs_fast(st, s->d, dc, dpx, (float *)tmp);
+            (void)es;
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipMemcpy(h.data(), tmp, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+            (void)hipFree(tmp);
+            std::fwrite(h.data(), sizeof(float), h.size(), f);
+            std::fclose(f);
+        }
+    }
     if (record_costs) {  // this frame's chunk times -> the next frame's tile order
         e = exact ? launch_order_tiles_exact(st, s->cost_dev, dp.n_tiles, s->order_dev) : launch_order_tiles_fast(st, s->cost_dev, dp.n_tiles, s->order_dev);
         if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "tile ordering launch failed: %s", hipGetErrorString(e));
@@ -651,7 +682,7 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
     if (!s->host_e0) HIP_TRY(hipEventCreate(&s->host_e0));
     if (!s->host_e1) HIP_TRY(hipEventCreate(&s->host_e1));
     const bool count = (p->flags & RAYHS_FLAG_COUNT) != 0;
-    if (count) HIP_TRY(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * CNT_SLOTS, nullptr));
+    if (count) HIP_TRY(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * CNT_SLOTS_DEV, nullptr));
     int rc = launch(s, cam, p, s->host_out_dev, nullptr, count ? (uint64_t *)s->counters : nullptr, s->host_e0, s->host_e1);
     if (rc) return rc;
     // the copy is ordered behind the kernels on the NULL stream and blocks the host until the frame is there
@@ -663,7 +694,7 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
         HIP_TRY(hipEventElapsedTime(&ms, s->host_e0, s->host_e1));
         stats->kernel_ms = ms;
         if (count) {
-            unsigned long long c[CNT_SLOTS];
+            unsigned long long c[CNT_SLOTS_DEV];
             HIP_TRY(hipMemcpy(c, s->counters, sizeof c, hipMemcpyDeviceToHost));
             stats->rays_primary = c[CNT_PRIMARY]; stats->rays_reflect = c[CNT_REFLECT]; stats->rays_refract = c[CNT_REFRACT];
             stats->rays_refract_exit = c[CNT_REFRACT_EXIT]; stats->rays_shadow = c[CNT_SHADOW];
@@ -672,6 +703,12 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
             stats->shaded_hits = c[CNT_SHADED]; stats->pixels = c[CNT_PIXELS] / (unsigned long long)std::max(p->spp, 1);  // the kernel counts samples
             if (std::getenv("RAYHS_DEBUG_COUNTERS"))  // development: raw loop counters of a -DRAYHS_PROFILE_LOOPS build
                 std::fprintf(stderr, "rayhs adv[0..3] %llu %llu %llu %llu span_ticks %llu latest_end %llu earliest_start %llu counters[6..15]: %llu %llu | %llu %llu | %llu %llu %llu %llu %llu %llu  kernel_ms %.3f\n", c[0], c[1], c[2], c[3], c[5] - ~c[4], c[5], ~c[4], c[6], c[7], c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], (double)ms);
+            if (std::getenv("RAYHS_DEBUG_COUNTERS"))  // (active lanes, wave executions) of: rounds, plane tests, plane divisions, sphere tests, hit, light, return sections, triangle tests
+                std::fprintf(stderr, "rayhs sections[16..31]: %llu %llu | %llu %llu | %llu %llu | %llu %llu | %llu %llu | %llu %llu | %llu %llu | %llu %llu\n", c[16], c[17], c[18], c[19],
+                             c[20], c[21], c[22], c[23], c[24], c[25], c[26], c[27], c[28], c[29], c[30], c[31]);
+            if (std::getenv("RAYHS_DEBUG_COUNTERS"))
+                std::fprintf(stderr, "rayhs traversal[32..39]: in-traversal %llu %llu | holding-leaf %llu %llu | lane-visits in passes <16 / <32 lanes: %llu %llu | entering %llu %llu\n",
+                             c[32], c[33], c[34], c[35], c[36], c[37], c[38], c[39]);
         }
     }
     return RAYHS_OK;

@@ -129,6 +129,7 @@ struct DParams {
     int32_t stripe_shift;             // log2(stripe_rows) when that is a power of two, else -1
     float inv_tiles_x;                // 1 / tiles_x: tile -> (row, column) of the tile grid without an integer division
     const int32_t *tile_order;        // work order of the 8x8 tiles, slowest first (NULL: scan order); from the previous frame's tile_cost
+    int32_t flags_dev, pad_dev;       // development switches of the helper kernels (bit 0: rayhs_static_costs emits its raw feature)
     float *tile_cost;                 // per tile: longest time (100 MHz ticks) one of its chunks took in THIS frame (NULL: not recorded)
 };
 
@@ -137,7 +138,8 @@ enum { CNT_PRIMARY = 0, CNT_REFLECT, CNT_REFRACT, CNT_REFRACT_EXIT, CNT_SHADOW, 
        CNT_PRIMS, CNT_SHADED, CNT_PIXELS,
        CNT_SHADOW_SKIPPED,  // shadow queries counted in CNT_SHADOW but not traced (zero light term); slot 10 doubles as a
                             // development counter in -DRAYHS_PROFILE_LOOPS / -DRAYHS_PROFILE_TIME builds
-       CNT_SLOTS = 16 };
+       CNT_SLOTS = 16,
+       CNT_SLOTS_DEV = 48 };  // development builds (-DRAYHS_PROFILE_LOOPS) also write slots 16..31: the library's own buffer holds 32
 
 static constexpr int TRACE_BLOCK = 256;     // threads per workgroup (4 waves)
 static constexpr int FRAME_SLOTS = 14;      // doubles per continuation frame

@@ -257,7 +257,12 @@ enum : int { FR_PLASTIC = 0, FR_MIRROR, FR_TRANS_WAIT_RADIANCE, FR_TRANS_WAIT_SP
 // query kinds
 enum : int { Q_NONE = 0, Q_CLOSEST, Q_SHADOW };
 
-struct Counters { unsigned long long c[16]; };
+#ifdef RAYHS_PROFILE_LOOPS
+constexpr int kCounterSlots = CNT_SLOTS_DEV;  // + (active lanes, wave executions) pairs of the shading sections and query loops
+#else
+constexpr int kCounterSlots = 16;
+#endif
+struct Counters { unsigned long long c[kCounterSlots]; };
 // development counters (slots 10..15, -DRAYHS_PROFILE_LOOPS): lane- and wave-level trip counts of the hot loops
 // -DRAYHS_PROFILE_TIME: the counting kernel is built like the production kernel (no work counters, same
 // occupancy) but lane 0 of every wave accumulates shader-clock cycles per phase into slots 10..15.
@@ -450,6 +455,7 @@ struct Tracer {
             const bool consider = active && (EXH || !(shadow && (occluded || !pl.occluder)));
             if (__ballot(consider) == 0ull) continue;
             if (COUNT && consider) cnt.c[CNT_PRIMS]++;
+            if (consider) { LOOP_TICK(18); }
             double num, den;
             plane_terms(pl, r, num, den);
             // a shadow query only asks whether the hit lies in front of the light: with an approximate quotient
@@ -461,6 +467,7 @@ struct Tracer {
             const bool beyond_light = shadow && point_light && s_far * (1.0 - 1e-4) > light_d2 && s_far > o_guard;
             const bool wanted = consider && quotient_may_be_positive(num, den) && !beyond_light;
             if (__ballot(wanted) == 0ull) continue;
+            if (wanted) { LOOP_TICK(20); }
             const double t = num / den;
             const bool hit = consider && fabs(den) > 0 && t > 0;
             if (wave_shadow != 0ull && __ballot(hit && shadow) != 0ull) {
@@ -476,6 +483,7 @@ struct Tracer {
             const bool consider = active && (EXH || !(shadow && (occluded || !s.occluder)));
             if (__ballot(consider) == 0ull) continue;
             if (COUNT && consider) cnt.c[CNT_PRIMS]++;
+            if (consider) { LOOP_TICK(22); }
             double b, delta, t = 0;
             sphere_terms(s, r, a, b, delta);
             if (__ballot(consider && !(delta < 0.0)) == 0ull) continue;
@@ -621,13 +629,24 @@ struct Tracer {
             const int obj = me.obj;
             stop_traversal();
             if (enter) t_cur = me.froot;
+            if (enter) { LOOP_TICK(38); }
             TIME_ADD(12);
             while (true) {
                 // phase 1: walk inner nodes until this lane holds a leaf (or runs out of nodes).  The body is
                 // branch-free apart from the stack push/pop: the whole 64-byte node is requested at once (one
                 // memory round trip per visit) and both child boxes are always tested.
+#ifdef RAYHS_PROFILE_LOOPS
+                if (COUNT) {  // per pass of the while-while loop: lanes still in this traversal (32), of which holding a leaf (34)
+                    if (traversing()) { LOOP_TICK(32); }
+                    if (t_pa != FNODE_NONE) { LOOP_TICK(34); }
+                }
+#endif
                 while (t_cur != FNODE_NONE && t_pa == FNODE_NONE) {
                     LOOP_TICK(10);
+#ifdef RAYHS_PROFILE_LOOPS
+                    if (COUNT) cnt.c[36] += (unsigned)__popcll(__ballot(true)) < 16u;   // lane-visits made in passes with < 16 lanes active
+                    if (COUNT) cnt.c[37] += (unsigned)__popcll(__ballot(true)) < 32u;   // ... < 32
+#endif
 #ifdef RAYHS_PROFILE_LOOPS
                     if (COUNT) {  // coherence probe: how many active lanes sit on the same node as the first active lane
                         const int leader = __builtin_amdgcn_readfirstlane(t_cur);
@@ -651,6 +670,7 @@ struct Tracer {
                     for (int k = first; k < first + n; k++) {
                         const DTri tr = rec(ftris, k);
                         if (COUNT) cnt.c[CNT_TRIS]++;
+                        LOOP_TICK(30);
                         double t, u, v;
                         if (tri_test(tr, r, t, u, v)) {
                             bool admitted = true;
@@ -679,7 +699,7 @@ struct Tracer {
 
 // ---- global per-lane workspace: LANE_SLOTS lane slots, then FRAME_SLOTS per continuation level ----
 enum : int { LS_V = 0, LS_TERM = 3 };
-enum : int { FS_KIND = 0, FS_DEPTH = 1, FS_F = 2, FS_S = 3, FS_K = 4, FS_A = 5, FS_RO = 8, FS_RD = 11 };
+enum : int { FS_KIND = 0 /* kind + 4 * depth */, FS_F = 2, FS_S = 3, FS_K = 4, FS_A = 5, FS_RO = 8, FS_RD = 11 };
 // slot-major: slot s of lane g sits at frames[s * stride + g]; addressed as uniform base + 32-bit byte offset
 struct Workspace { double *base; unsigned stride, lane; };
 DEV double *ws_at(const Workspace &ws, int slot) {
@@ -704,14 +724,16 @@ DEV V3 cx_load3(lds_dptr cx, int slot) { return mk(cx[slot * TRACE_BLOCK], cx[(s
 #define PARK_TERM(v) do { if (term_in_lds) cx_store3(cx, CX_TERM, v); else ws_store3(ws, LS_TERM, v); } while (0)
 #define LOAD_TERM() (term_in_lds ? cx_load3(cx, CX_TERM) : ws_load3(ws, LS_TERM))
 
+// always inlined into its kernel: the body reads the kernarg segment of the kernel it belongs to (kargs()), which an
+// out-of-line copy shared by two kernels of one instantiation cannot
 template <bool EXH, bool COUNT, typename StackT>
-static __device__ void trace_body() {
+static __device__ __forceinline__ void trace_body() {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int gtid = blockIdx.x * TRACE_BLOCK + tid;
     Counters cnt;
-    for (int i = 0; i < 16; i++) cnt.c[i] = 0;
+    for (int i = 0; i < kCounterSlots; i++) cnt.c[i] = 0;
     lds_dptr cx = (lds_dptr)lds + tid;                                                  // context column
     typedef StackT __attribute__((address_space(3))) *stack_ptr;
     const int ctx_slots = PRM.ctx_slots;
@@ -807,10 +829,12 @@ static __device__ void trace_body() {
                 }
                 if (exhausted) break;
                 if (lane == 0) ticket_ahead = atomicAdd(ticket + range * 8, (unsigned long long)kChunk);
+                // a chunk (64 consecutive items, 64-aligned) never straddles tiles: its tile is wave-uniform and comes
+                // through the scalar cache, in the order the previous frame measured, slowest first (rayhs_order_tiles)
+                const unsigned tslot = prm.spp_shift >= 0 ? (unsigned)(pool_next >> (prm.spp_shift + 6)) : (unsigned)(pool_next / ((unsigned long long)prm.spp * 64ull));
+                const int entry = prm.tile_order ? as_const(prm.tile_order)[tslot] : (int)tslot;
+                chunk_tile = entry & kTileMask;
                 if (prm.tile_cost != nullptr) {
-                    const unsigned tslot = (unsigned)(pool_next / ((unsigned long long)prm.spp * 64ull));
-                    const int entry = prm.tile_order ? as_const(prm.tile_order)[tslot] : (int)tslot;
-                    chunk_tile = entry & kTileMask;
                     chunk_t0 = __builtin_amdgcn_s_memrealtime();
                     // the slower the tile was last time, the higher this wave's issue priority while it works on it: a
                     // chunk is a chain of dependent queries, and when a frame is small (one GPU's share of eight) the
@@ -836,8 +860,7 @@ static __device__ void trace_body() {
                 // reciprocal where the operands allow it)
                 const unsigned slot = prm.spp_shift >= 0 ? (unsigned)(item >> prm.spp_shift) : (unsigned)(item / (unsigned)prm.spp);
                 sample = (int)(item - (unsigned long long)slot * (unsigned)prm.spp);
-                // tiles are worked in the order the previous frame measured, slowest first (see rayhs_order_tiles)
-                const int tile = prm.tile_order ? (prm.tile_order[slot >> 6] & kTileMask) : (int)(slot >> 6);
+                const int tile = chunk_tile;
                 const int within = (int)(slot & 63u);
                 int ty = (int)((float)tile * prm.inv_tiles_x), tx = tile - ty * prm.tiles_x;  // tile < 2^24: off by one at most
                 if (tx < 0) { ty--; tx += prm.tiles_x; } else if (tx >= prm.tiles_x) { ty++; tx -= prm.tiles_x; }
@@ -871,6 +894,7 @@ static __device__ void trace_body() {
         qkind = Q_NONE;
         occluded = tr.occ;
         if (state != ST_DONE) {
+            LOOP_TICK(16);
             V3 result = mk(0, 0, 0);
             V3 c_p = mk(0, 0, 0), c_n = mk(0, 0, 0), c_cd = mk(0, 0, 0), c_A = mk(0, 0, 0);
             enum : int { A_NONE, A_LIGHT_NEXT, A_SPEC, A_RETURN, A_QUERY_READY };
@@ -878,6 +902,7 @@ static __device__ void trace_body() {
             bool spec_with_A = false;
 
             if (state == ST_HIT) {
+                LOOP_TICK(24);
                 // traceRay (src/RayHs.hs:149-154)
                 if (tr.bobj < 0) { result = mk(0, 0, 0); step = A_RETURN; }
                 else {
@@ -911,6 +936,8 @@ static __device__ void trace_body() {
                     if (mat_kind == 1 || mat_kind == 2) {  // Diffuse, Plastic
                         c_cd = ob.cmap_kind == 0 ? ld3(ob.c1) : color_at_slow(as_const(SC.objects), tr.bobj, SC.texels, hu, hv);
                         c_A = mk(0, 0, 0); c_li = 0;
+                        // the context of the hit being shaded waits in LDS while its shadow rays are traced (A is added per light)
+                        cx_store3(cx, CX_P, c_p); cx_store3(cx, CX_N, c_n); cx_store3(cx, CX_CD, c_cd);
                         step = A_LIGHT_NEXT;
                     } else if (mat_kind == 0) {  // Mirror
                         spec_with_A = false; step = A_SPEC;
@@ -953,8 +980,7 @@ static __device__ void trace_body() {
                         // suspend this irradiance call: radiance child first, specular child later
                         V3 c_v = LOAD_V();
                         V3 rf = reflect(c_v, c_n);
-                        ws_store(ws, fslot(fsp, FS_KIND), (double)FR_TRANS_WAIT_RADIANCE);
-                        ws_store(ws, fslot(fsp, FS_DEPTH), (double)depth);
+                        ws_store(ws, fslot(fsp, FS_KIND), (double)(FR_TRANS_WAIT_RADIANCE + 4 * depth));
                         ws_store(ws, fslot(fsp, FS_F), fresnel(ob.fr, dot(c_n, neg(c_v))));
                         ws_store(ws, fslot(fsp, FS_S), dot(rf, c_n));
                         ws_store(ws, fslot(fsp, FS_K), ob.one_m_r0);
@@ -972,6 +998,7 @@ static __device__ void trace_body() {
 
             TIME_ADD(1);  // hit / shadow / exit sections
             while (step == A_LIGHT_NEXT) {  // per lane; more than one pass only when a light's term is exactly zero
+                LOOP_TICK(26);
                 if (c_li < SC.n_lights) {
                     // lightAt (src/Light.hs:12-17) + diffuse (src/Material.hs:31-33)
                     const auto &L = rec(SC.lights, c_li);
@@ -1001,8 +1028,7 @@ static __device__ void trace_body() {
                     ray.o = add(c_p, scl(kEps, ld)); ray.d = ld;  // rayEps p ld
                     if (q_point) { V3 dd = sub(ray.o, ld3(L.v)); q_d2 = dot(dd, dd); }  // sqrDist origin p (src/RayHs.hs:87)
                     if (COUNT) cnt.c[CNT_SHADOW]++;
-                    // park the context of the hit being shaded while its shadow ray is traced
-                    cx_store3(cx, CX_P, c_p); cx_store3(cx, CX_N, c_n); cx_store3(cx, CX_CD, c_cd); cx_store3(cx, CX_A, c_A);
+                    cx_store3(cx, CX_A, c_A);  // p, n, cd were parked when the hit was found
                     qkind = Q_SHADOW; state = ST_SHADOW; step = A_QUERY_READY;
                 } else if (rec(SC.objects, c_obj).mat_kind == 1) {
                     result = add(scl(0.2, c_cd), c_A);  // Diffuse (src/RayHs.hs:111-114)
@@ -1021,8 +1047,7 @@ static __device__ void trace_body() {
                 double F = fresnel(ob.fr, dot(c_n, neg(c_v)));
                 if (depth < PRM.max_depth) {
                     V3 rf = reflect(c_v, c_n);
-                    ws_store(ws, fslot(fsp, FS_KIND), (double)(spec_with_A ? FR_PLASTIC : FR_MIRROR));
-                    ws_store(ws, fslot(fsp, FS_DEPTH), (double)depth);
+                    ws_store(ws, fslot(fsp, FS_KIND), (double)((spec_with_A ? FR_PLASTIC : FR_MIRROR) + 4 * depth));
                     ws_store(ws, fslot(fsp, FS_F), F);
                     ws_store(ws, fslot(fsp, FS_S), dot(rf, c_n));
                     if (spec_with_A) ws_store3(ws, fslot(fsp, FS_A), c_A);
@@ -1041,6 +1066,7 @@ static __device__ void trace_body() {
             TIME_ADD(3);  // specular section
             // hand `result` to the suspended callers until one needs another ray, or the sample is done
             while (step == A_RETURN) {
+                LOOP_TICK(28);
                 if (fsp == 0) {
                     const size_t pix = (size_t)lrow * (size_t)PRM.width + (size_t)px;
                     if (PRM.wave_resolve) {
@@ -1057,25 +1083,28 @@ static __device__ void trace_body() {
                     step = A_NONE;
                 } else {
                     int lv = fsp - 1;
-                    int kind = (int)ws_load(ws, fslot(lv, FS_KIND));
-                    double F = ws_load(ws, fslot(lv, FS_F)), S = ws_load(ws, fslot(lv, FS_S));
+                    // one batch of loads per level (a single memory round trip): what every kind but MIRROR reads
+                    const int kd = (int)ws_load(ws, fslot(lv, FS_KIND));
+                    const double F = ws_load(ws, fslot(lv, FS_F)), S = ws_load(ws, fslot(lv, FS_S));
+                    const V3 fA = ws_load3(ws, fslot(lv, FS_A));
+                    const int kind = kd & 3;
                     if (kind == FR_PLASTIC) {
-                        result = add(ws_load3(ws, fslot(lv, FS_A)), scl(F, scl(S, result)));
+                        result = add(fA, scl(F, scl(S, result)));
                         fsp = lv;
                     } else if (kind == FR_MIRROR) {
                         result = scl(F, scl(S, result));
                         fsp = lv;
                     } else if (kind == FR_TRANS_WAIT_RADIANCE) {
                         ws_store3(ws, fslot(lv, FS_A), result);
-                        ws_store(ws, fslot(lv, FS_KIND), (double)FR_TRANS_WAIT_SPEC);
+                        ws_store(ws, fslot(lv, FS_KIND), (double)(FR_TRANS_WAIT_SPEC + (kd & ~3)));
                         ray.o = ws_load3(ws, fslot(lv, FS_RO));
                         ray.d = ws_load3(ws, fslot(lv, FS_RD));
-                        depth = (int)ws_load(ws, fslot(lv, FS_DEPTH)) + 1;
+                        depth = (kd >> 2) + 1;
                         if (COUNT) cnt.c[CNT_REFLECT]++;
                         qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
                     } else {
                         double K = ws_load(ws, fslot(lv, FS_K));
-                        result = add(scl(K, ws_load3(ws, fslot(lv, FS_A))), scl(F, scl(S, result)));
+                        result = add(scl(K, fA), scl(F, scl(S, result)));
                         fsp = lv;
                     }
                 }
@@ -1123,7 +1152,7 @@ static __device__ void trace_body() {
     unsigned long long *const counters = kargs()->counters;
 #endif
     if ((COUNT || kProfileTime) && counters != nullptr) {
-        for (int i = 0; i < 16; i++) {
+        for (int i = 0; i < kCounterSlots; i++) {
             unsigned long long v = cnt.c[i];
             if (kProfileTime && (i == 4 || i == 5)) continue;
             if (kProfileTime && (i >= 6 || i < 4) && lane != 0) v = 0;  // per-wave values: lane 0 only
@@ -1206,6 +1235,117 @@ RAYHS_CAT(rayhs_order_tiles, RAYHS_KERNEL_SUFFIX)(float *cost, int n, int *order
     }
 }
 
+// Work order of the FIRST frame of a geometry, which has no measured chunk times yet (and is the only frame a one-shot
+// `rayhs -oX scene.json` renders, src/RayHs.hs:215-234): a static estimate per 8x8 tile.  One thread per tile looks
+// through the tile's centre and its four corners.  Rays that meet a mesh's root box (the reference root's box,
+// inflated) make the tile expensive in proportion to their number -- those chunks walk the BVH, and their shadow and
+// reflection rays start inside it.  The surface the centre ray sees first adds the rest: a reflective or refractive
+// material spawns secondary rays (more when the mirrored ray heads for a mesh), and every light whose shadow segment
+// crosses a mesh box costs a traversal.  rayhs_order_tiles turns the estimate into the same slowest-first order and
+// issue priorities as a measured frame.  Scheduling only: nothing here enters a pixel.
+namespace rayhs {
+DEV bool hits_mesh_box(const DMesh &me, V3 o, V3 d, double t_limit) {
+    double tmin = -__builtin_inf(), tmax = __builtin_inf();
+    const double oo[3] = {o.x, o.y, o.z}, iv[3] = {1 / d.x, 1 / d.y, 1 / d.z};
+    for (int a = 0; a < 3; a++) {
+        const double pad = 0.02 * (me.hi[a] - me.lo[a]) + 1e-9;
+        const double t1 = (me.lo[a] - pad - oo[a]) * iv[a], t2 = (me.hi[a] + pad - oo[a]) * iv[a];
+        tmin = fmax(tmin, fmin(t1, t2)); tmax = fmin(tmax, fmax(t1, t2));  // fmin / fmax drop a NaN (0 * inf): that axis then does not cull
+    }
+    return tmax >= fmax(tmin, 0.0) && tmin <= t_limit;
+}
+// How many boxes of the upper kStaticDepth levels of a mesh's BVH the ray meets: a cheap stand-in for "how much of the
+// mesh is along this ray" (the root box alone is mostly empty space around the model).
+constexpr int kStaticDepth = 9;
+DEV int upper_boxes_met(const DScene &sc, const DMesh &me, V3 o, V3 d) {
+    const float ox = (float)(o.x - me.center[0]), oy = (float)(o.y - me.center[1]), oz = (float)(o.z - me.center[2]);
+    const float ix = 1.0f / (float)d.x, iy = 1.0f / (float)d.y, iz = 1.0f / (float)d.z;
+    int stack[kStaticDepth + 1], depth[kStaticDepth + 1], sp = 0, met = 0;
+    stack[sp] = me.froot; depth[sp] = 0; sp++;
+    while (sp > 0) {
+        sp--;
+        const int node = stack[sp], dep = depth[sp];
+        const FNode &nd = sc.fnodes[node];
+        for (int ch = 0; ch < 2; ch++) {
+            const float *b = ch ? nd.b1 : nd.b0;
+            const int c = ch ? nd.c1 : nd.c0;
+            if (c == FNODE_NONE) continue;
+            const float t1 = (b[0] - ox) * ix, t2 = (b[1] - ox) * ix, t3 = (b[2] - oy) * iy, t4 = (b[3] - oy) * iy, t5 = (b[4] - oz) * iz, t6 = (b[5] - oz) * iz;
+            const float tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6)), tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+            if (!(tf >= fmaxf(tn, 0.0f))) continue;
+            met++;
+            if (c >= 0 && dep + 1 < kStaticDepth && sp <= kStaticDepth) { stack[sp] = c; depth[sp] = dep + 1; sp++; }
+        }
+    }
+    return met;
+}
+}  // namespace rayhs
+extern "C" __global__ void __launch_bounds__(256)
+RAYHS_CAT(rayhs_static_costs, RAYHS_KERNEL_SUFFIX)(DScene sc, DCamera cam, DParams prm, float *cost) {
+    const int tile = blockIdx.x * 256 + threadIdx.x;
+    if (tile >= prm.n_tiles) return;
+    const int ty = tile / prm.tiles_x, tx = tile - ty * prm.tiles_x;
+    auto image_row = [&](int lrow) {  // local row -> image row (stripe interleave, as in the trace kernel)
+        if (prm.stripe_count == 1) return prm.row0 + lrow;
+        const int s_local = lrow / prm.stripe_rows, in_stripe = lrow - s_local * prm.stripe_rows;
+        return prm.row0 + (s_local * prm.stripe_count + prm.stripe_rank) * prm.stripe_rows + in_stripe;
+    };
+    const int x0 = tx * 8, x1 = min(x0 + 8, prm.width), l0 = ty * 8, l1 = min(l0 + 8, prm.n_rows);
+    const double ytop = (double)image_row(l0), ybot = (double)image_row(l1 - 1) + 1.0;
+    const double inf = __builtin_inf();
+    float c = 1.0f;
+    int box_rays = 0, boxes_met = 0;
+    for (int k = 0; k < 5; k++) {
+        // sample offsets reach half a pixel beyond the pixel corners (src/RayHs.hs:178-188): look half a pixel wider
+        const double fx = k == 0 ? 0.5 * (double)(x0 + x1) : ((k & 1) ? (double)x0 - 0.5 : (double)x1 + 0.5);
+        const double fy = k == 0 ? 0.5 * (ytop + ybot) : ((k & 2) ? ytop - 0.5 : ybot + 0.5);
+        const Ray r = ray_from_pixel(cam, fx, fy);
+        bool in_box = false;
+        for (int m = 0; m < sc.n_meshes; m++)
+            if (sc.meshes[m].froot != FNODE_NONE && hits_mesh_box(sc.meshes[m], r.o, r.d, inf)) { in_box = true; boxes_met += upper_boxes_met(sc, sc.meshes[m], r.o, r.d); }
+        box_rays += in_box ? 1 : 0;
+        if (k != 0) continue;
+        // the first analytic surface the centre ray meets (approximate is enough: it only picks a class)
+        double best = inf;
+        int obj = -1;
+        V3 nrm = mk(0, 0, 0);
+        for (int i = 0; i < sc.n_planes; i++) {
+            const DPlane &pl = sc.planes[i];
+            const double den = dot(r.d, ld3(pl.n)), t = dot(ld3(pl.n), sub(ld3(pl.p), r.o)) / den;
+            if (fabs(den) > 0 && t > 0 && t < best) { best = t; obj = pl.obj; nrm = ld3(pl.n); }
+        }
+        for (int i = 0; i < sc.n_spheres; i++) {
+            const DSphere &sp = sc.spheres[i];
+            const V3 oc = sub(r.o, ld3(sp.c));
+            const double a = dot(r.d, r.d), b = 2.0 * dot(r.d, oc), cc = dot(oc, oc) - sp.r2, delta = b * b - 4.0 * a * cc;
+            if (delta < 0) continue;
+            const double sq = sqrt(delta), t0 = 0.5 * (-b - sq) / a, t1 = 0.5 * (-b + sq) / a, t = t0 > 0 ? t0 : t1;
+            if (t > 0 && t < best) { best = t; obj = sp.obj; nrm = sub(add(r.o, scl(t, r.d)), ld3(sp.c)); }
+        }
+        if (obj < 0) continue;
+        const V3 p = add(r.o, scl(best, r.d));
+        const int mk_ = sc.objects[obj].mat_kind;  // Mirror 0, Diffuse 1, Plastic 2, Transparent 4 (src/RayHs.hs:107-143)
+        if (mk_ == 1 || mk_ == 2)  // one shadow query per light; the ones that cross a mesh box walk its BVH
+            for (int li = 0; li < sc.n_lights; li++) {
+                const DLight &L = sc.lights[li];
+                const V3 d = L.kind == 0 ? ld3(L.v) : sub(ld3(L.v), p);
+                for (int m = 0; m < sc.n_meshes; m++)
+                    if (sc.meshes[m].froot != FNODE_NONE && hits_mesh_box(sc.meshes[m], p, d, L.kind == 0 ? inf : 1.0)) { c += 0.25f; break; }
+            }
+        if (mk_ == 0 || mk_ == 2 || mk_ == 4) {
+            c += mk_ == 4 ? 4.0f : 2.5f;
+            const V3 n = unit(nrm), rf = reflect(r.d, n);
+            for (int m = 0; m < sc.n_meshes; m++)
+                if (sc.meshes[m].froot != FNODE_NONE && hits_mesh_box(sc.meshes[m], add(p, scl(1e-6, rf)), rf, inf)) { c += 3.0f; break; }
+        }
+    }
+    // weights fitted to the chunk times a measured frame records (dragon scenes, profiles/r02/static_costs.md): in units of a
+    // diffuse wall tile, a tile is worth ~3 when its rays only graze the upper boxes and up to ~17 deep inside the model
+    if (box_rays > 0) c += boxes_met < 40 ? 0.045f * (float)boxes_met : fminf(16.0f, 1.8f + 0.26f * (float)(boxes_met - 40));
+    if (prm.flags_dev & 1) c = (float)boxes_met;  // development: dump the raw feature (RAYHS_DUMP_TILE_COSTS)
+    cost[tile] = c;
+}
+
 RAYHS_DEFINE_KERNEL(rayhs_trace, false, false, unsigned short, RAYHS_WAVES_PER_EU)       // < 65536 BVH nodes
 RAYHS_DEFINE_KERNEL(rayhs_trace_wide, false, false, unsigned int, RAYHS_WAVES_PER_EU)   // any scene
 #ifdef RAYHS_PROFILE_TIME
@@ -1235,6 +1375,10 @@ hipError_t RAYHS_CAT(launch_trace, RAYHS_KERNEL_SUFFIX)(int variant, int grid, s
 }
 hipError_t RAYHS_CAT(launch_resolve, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format) {
     hipLaunchKernelGGL(RAYHS_CAT(rayhs_resolve, RAYHS_KERNEL_SUFFIX), dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream, sbuf, out, n_pixels, spp, out_format);
+    return hipGetLastError();
+}
+hipError_t RAYHS_CAT(launch_static_costs, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, const DScene &sc, const DCamera &cam, const DParams &prm, float *cost) {
+    hipLaunchKernelGGL(RAYHS_CAT(rayhs_static_costs, RAYHS_KERNEL_SUFFIX), dim3((unsigned)((prm.n_tiles + 255) / 256)), dim3(256), 0, stream, sc, cam, prm, cost);
     return hipGetLastError();
 }
 hipError_t RAYHS_CAT(launch_order_tiles, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, float *cost, int n, int *order) {
