@@ -213,6 +213,32 @@ int rayhs_render_device_events(const rayhs_scene *scene, const rayhs_camera *cam
                                const rayhs_render_params *params, void *d_out, void *hip_stream,
                                uint64_t *d_counters, void *ev_before_trace, void *ev_after_trace);
 
+/* ---- several GPUs of one node, one process -------------------------------
+ * What replaces the reference's parallel pixel map (generatePixels over GHC
+ * sparks, src/Image.hs:34-36): the rows [row0, row1) are cut into stripes of
+ * params->stripe_rows rows (8 if < 1), every listed device traces its share of
+ * them from its own copy of the scene, and pushes the finished stripes into
+ * the whole frame on devices[0] with peer writes (xGMI).  No collective on the
+ * data path: stripes are independent.  Ownership of the stripes is balanced by
+ * a static cost estimate of the frame (the model sits in the middle rows), not
+ * dealt round-robin; params->stripe_rank / stripe_count are ignored.  The
+ * frame is bit-identical to the single-device one.  `devices` may name a
+ * device more than once (a one-GPU rehearsal of the N-GPU path).  The same
+ * one-thread-at-a-time rule as for scene handles applies. */
+typedef struct rayhs_multi rayhs_multi;
+int rayhs_multi_create(const rayhs_scene_desc *desc, const int *devices, int n_devices, rayhs_multi **out);
+void rayhs_multi_destroy(rayhs_multi *multi);
+int rayhs_multi_device_count(const rayhs_multi *multi);
+/* Whole frame (rows row0..row1) into a HOST buffer of (row1-row0)*width*3 elements; synchronous.
+ * stats (may be NULL): counters summed over the devices, kernel_ms = the slowest device's trace kernel. */
+int rayhs_multi_render(rayhs_multi *multi, const rayhs_camera *camera, const rayhs_render_params *params,
+                       void *out_host, rayhs_stats *stats);
+/* Same into a DEVICE buffer that lives on devices[0]; synchronous. */
+int rayhs_multi_render_device(rayhs_multi *multi, const rayhs_camera *camera, const rayhs_render_params *params,
+                              void *d_out, rayhs_stats *stats);
+/* After a render: the estimated share of the frame's cost (0..1) and the rows given to each device. Either may be NULL. */
+int rayhs_multi_shares(const rayhs_multi *multi, double *shares, int *rows, int n);
+
 /* ---- host preparation (C++ restatement of the reference's L3/L4 host code;
  * the Haskell host would do this itself and call rayhs_scene_create) -------- */
 

@@ -6,4 +6,4 @@ oilandrust/rayhs, behind the C ABI of include/rayhs.h.
     api.py  RenderDesc / Rendering / ray_trace mirroring src/RayHs.hs
 """
 from . import lib  # noqa: F401
-from .api import RenderDesc, Rendering, build_rendering, ray_trace_file, run_cli, write_ppm  # noqa: F401
+from .api import MultiRendering, RenderDesc, Rendering, build_rendering, ray_trace_file, run_cli, write_ppm  # noqa: F401

@@ -144,6 +144,49 @@ class Rendering:
         self.close()
 
 
+class MultiRendering:
+    """One frame over several GPUs of the node from one process (rayhs_multi, include/rayhs.h): the replacement for
+    the reference's parallel pixel map (src/Image.hs:34-36).  `devices` may repeat a device (rehearsal)."""
+
+    def __init__(self, desc, devices, width=None, height=None, max_depth=None):
+        lib = L.load()
+        self.desc = desc
+        self.width = desc.width if width is None else width
+        self.height = desc.height if height is None else height
+        self.max_depth = desc.max_depth if max_depth is None else max_depth
+        self.devices = list(devices)
+        h = C.c_void_p()
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        L.check(lib.rayhs_multi_create(C.byref(desc.scene_desc), arr, len(self.devices), C.byref(h)))
+        self._h = h
+
+    def ray_trace(self, spp=1, seed=24, row0=0, row1=None, stripe_rows=8, out_format=L.OUT_F64, flags=0):
+        p = L.RenderParams()
+        p.width, p.height, p.max_depth = self.width, self.height, self.max_depth
+        p.spp, p.seed, p.row0 = spp, seed, row0
+        p.row1 = self.height if row1 is None else row1
+        p.stripe_rows, p.stripe_rank, p.stripe_count = stripe_rows, 0, 1
+        p.out_format, p.flags = out_format, flags
+        out = np.empty((p.row1 - p.row0, self.width, 3), dtype=_NP[out_format])
+        st = L.Stats()
+        L.check(L.load().rayhs_multi_render(self._h, C.byref(self.desc.camera), C.byref(p), out.ctypes.data, C.byref(st)))
+        return out, st.as_dict()
+
+    def shares(self):
+        n = len(self.devices)
+        sh, rows = (C.c_double * n)(), (C.c_int * n)()
+        L.check(L.load().rayhs_multi_shares(self._h, sh, rows, n))
+        return list(sh), list(rows)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.load().rayhs_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
 def build_rendering(path, device=0, **overrides):
     """buildRendering (src/RayHs.hs:47-50)."""
     return Rendering(RenderDesc(path), device, **overrides)

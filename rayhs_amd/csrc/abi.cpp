@@ -3,6 +3,7 @@
 // every compute entry point needs a HIP device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -22,6 +23,8 @@ hipError_t launch_trace_fast(int variant, int grid, size_t lds_bytes, hipStream_
 hipError_t launch_resolve_fast(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format);
 hipError_t launch_resolve_exact(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format);
 hipError_t launch_order_tiles_fast(hipStream_t stream, float *cost, int n, int *order);
+hipError_t launch_scatter_stripes_fast(hipStream_t stream, const void *src, void *dst, const int *stripe_map, int n_rows, int stripe_rows, long long row_bytes);
+hipError_t launch_scatter_stripes_exact(hipStream_t stream, const void *src, void *dst, const int *stripe_map, int n_rows, int stripe_rows, long long row_bytes);
 hipError_t launch_static_costs_fast(hipStream_t stream, const DScene &sc, const DCamera &cam, const DParams &prm, float *cost);
 hipError_t launch_static_costs_exact(hipStream_t stream, const DScene &sc, const DCamera &cam, const DParams &prm, float *cost);
 hipError_t launch_order_tiles_exact(hipStream_t stream, float *cost, int n, int *order);
@@ -459,14 +462,19 @@ static void make_camera(const rayhs_camera &c, int width, int height, DCamera &o
     o.proj_kind = c.proj_kind;
 }
 
-static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_render_params *p, DCamera &dc, DParams &dp,
+// An explicit list of the stripes one launch renders (rayhs_multi: cost-balanced ownership) instead of the round-robin
+// rule of rayhs_render_params.  d_map: device array of global stripe indices, ascending; rows: image rows they cover;
+// id: tells one list from another in the tile-order cache.
+struct StripeList { const int32_t *d_map = nullptr; int n_stripes = 0, rows = 0, id = 0; };
+
+static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_render_params *p, const StripeList *sl, DCamera &dc, DParams &dp,
                           int &variant, bool &exact, int &grid, size_t &lds) {
     if (!s || !cam || !p) return set_error(RAYHS_ERR_INVALID, "NULL argument");
     if (p->width <= 0 || p->height <= 0 || p->max_depth < 0 || p->spp < 1) return set_error(RAYHS_ERR_INVALID, "bad width/height/maxDepth/spp");
     if (p->row1 > p->height) return set_error(RAYHS_ERR_INVALID, "row1 beyond the image");
     if (p->out_format < RAYHS_OUT_F32 || p->out_format > RAYHS_OUT_I16) return set_error(RAYHS_ERR_INVALID, "bad out_format");
     if (cam->proj_kind != RAYHS_PROJ_ORTHOGRAPHIC && cam->proj_kind != RAYHS_PROJ_PERSPECTIVE) return set_error(RAYHS_ERR_INVALID, "bad projection kind");
-    int rows = rayhs_render_rows(p);
+    int rows = sl ? sl->rows : rayhs_render_rows(p);
     if (rows < 0) return rows;
     if ((p->flags & RAYHS_FLAG_EXHAUSTIVE) && !(p->flags & RAYHS_FLAG_COUNT)) return set_error(RAYHS_ERR_INVALID, "RAYHS_FLAG_EXHAUSTIVE needs RAYHS_FLAG_COUNT");
     make_camera(*cam, p->width, p->height, dc);
@@ -474,6 +482,7 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     dp.width = p->width; dp.height = p->height; dp.max_depth = p->max_depth; dp.spp = p->spp; dp.seed = p->seed;
     dp.row0 = p->row0; dp.n_rows = rows;
     dp.stripe_rows = p->stripe_rows; dp.stripe_rank = p->stripe_rank; dp.stripe_count = p->stripe_count;
+    if (sl) { dp.stripe_map = sl->d_map; dp.stripe_rank = sl->id; dp.stripe_count = 0; }  // rank / count are unused with a list (the rank slot keys the tile-order cache)
     dp.out_format = p->out_format;
     // samples of a pixel are folded inside the wave when they all sit in one 64-item chunk (trace_kernel.hip)
     dp.wave_resolve = (p->spp > 1 && 64 % p->spp == 0 && !std::getenv("RAYHS_NO_WAVE_RESOLVE")) ? 1 : 0;
@@ -553,6 +562,7 @@ static int ensure_workspace(const rayhs_scene *s, const DParams &dp) {
 // geometry -- the only one a one-shot `rayhs -oX scene.json` renders -- is ordered by a static estimate instead
 // (rayhs_static_costs: mesh-box tiles first, reflective surfaces next).  Nothing is read back to the host.
 static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, int variant, DParams &dp, hipStream_t st, bool &record, bool &need_static) {
+    // (dp.stripe_rank / dp.stripe_count carry the stripe list's id / 0 when the launch has an explicit list)
     dp.tile_order = nullptr; dp.tile_cost = nullptr; record = false; need_static = false;
 #ifdef RAYHS_PROFILE_TIME
     const bool production = variant != 2;  // the diagnostic build's "counting" kernel is the production kernel with time stamps
@@ -560,7 +570,7 @@ static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, i
     const bool production = variant == 0 || variant == 3;
 #endif
     if (!production || dp.n_tiles < 512 || std::getenv("RAYHS_SCAN_ORDER")) return RAYHS_OK;
-    const int key[10] = {p->width, p->height, p->row0, p->row1, p->stripe_rows, p->stripe_rank, p->stripe_count, p->spp, p->max_depth, dp.n_tiles};
+    const int key[10] = {p->width, p->height, p->row0, p->row1, p->stripe_rows, dp.stripe_rank, dp.stripe_count, p->spp, p->max_depth, dp.n_tiles};
     if (std::memcmp(key, s->order_key, sizeof key) != 0) {
         s->order_valid = false;
         if ((size_t)dp.n_tiles > s->order_cap) {
@@ -586,9 +596,9 @@ static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, i
 }
 
 static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_render_params *p, void *d_out, hipStream_t st,
-                  uint64_t *d_counters, hipEvent_t e0, hipEvent_t e1) {
+                  uint64_t *d_counters, hipEvent_t e0, hipEvent_t e1, const StripeList *sl = nullptr) {
     DCamera dc; DParams dp; int variant, grid; bool exact; size_t lds;
-    int rc = prepare_launch(s, cam, p, dc, dp, variant, exact, grid, lds);
+    int rc = prepare_launch(s, cam, p, sl, dc, dp, variant, exact, grid, lds);
     if (rc) return rc;
     if (!d_out) return set_error(RAYHS_ERR_INVALID, "d_out is NULL");
     if ((variant == 1 || variant == 2) && !d_counters) return set_error(RAYHS_ERR_INVALID, "RAYHS_FLAG_COUNT needs d_counters");
@@ -712,6 +722,272 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
         }
     }
     return RAYHS_OK;
+}
+
+// ------------------------------------------------------------ several GPUs, one process
+// The reference's only parallel construct is the pixel map (generatePixels, src/Image.hs:34-36).  Here the rows of one
+// frame are cut into stripes, every GPU of the node traces its share from its own copy of the scene (no collective on
+// the data path: stripes are independent), and pushes the finished stripes into the whole frame on the first GPU with
+// peer writes over xGMI.  Stripe ownership is balanced by the static tile estimate (rayhs_static_costs), not dealt
+// round-robin: the model sits in the middle rows.
+struct rayhs_multi {
+    std::vector<int> devices;
+    std::vector<rayhs_scene *> scenes;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> e0, e1, done;
+    std::vector<void *> out_dev;          // compact stripes of each device
+    std::vector<size_t> out_bytes;
+    std::vector<int32_t *> map_dev;
+    std::vector<size_t> map_cap;
+    std::vector<unsigned long long *> counters;
+    std::vector<StripeList> lists;
+    std::vector<double> est_share;         // estimated share of the frame's cost per device (last plan)
+    void *frame = nullptr;                 // whole frame, on devices[0]
+    size_t frame_bytes = 0;
+    float *cost0 = nullptr;                // static estimate of the whole frame, on devices[0]
+    size_t cost_cap = 0;
+    std::vector<unsigned char> plan_key;   // geometry + camera the stripe lists were planned for
+    int next_list_id = 1;
+};
+
+extern "C" void rayhs_multi_destroy(rayhs_multi *m) {
+    if (!m) return;
+    for (size_t i = 0; i < m->devices.size(); i++) {
+        (void)hipSetDevice(m->devices[i]);
+        if (i < m->streams.size() && m->streams[i]) { (void)hipStreamSynchronize(m->streams[i]); (void)hipStreamDestroy(m->streams[i]); }
+        if (i < m->e0.size() && m->e0[i]) (void)hipEventDestroy(m->e0[i]);
+        if (i < m->e1.size() && m->e1[i]) (void)hipEventDestroy(m->e1[i]);
+        if (i < m->done.size() && m->done[i]) (void)hipEventDestroy(m->done[i]);
+        if (i < m->out_dev.size() && m->out_dev[i]) (void)hipFree(m->out_dev[i]);
+        if (i < m->map_dev.size() && m->map_dev[i]) (void)hipFree(m->map_dev[i]);
+        if (i < m->counters.size() && m->counters[i]) (void)hipFree(m->counters[i]);
+        if (i < m->scenes.size() && m->scenes[i]) rayhs_scene_destroy(m->scenes[i]);
+    }
+    if (!m->devices.empty()) (void)hipSetDevice(m->devices[0]);
+    if (m->frame) (void)hipFree(m->frame);
+    if (m->cost0) (void)hipFree(m->cost0);
+    delete m;
+}
+
+extern "C" int rayhs_multi_create(const rayhs_scene_desc *desc, const int *devices, int n_devices, rayhs_multi **out) {
+    if (!out) return set_error(RAYHS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!devices || n_devices < 1 || n_devices > 64) return set_error(RAYHS_ERR_INVALID, "need 1..64 devices");
+    int ndev = rayhs_device_count();
+    if (ndev <= 0) return set_error(RAYHS_ERR_NO_DEVICE, "no HIP device available (librayhs_hip has no CPU fallback)");
+    for (int i = 0; i < n_devices; i++)
+        if (devices[i] < 0 || devices[i] >= ndev) return set_error(RAYHS_ERR_INVALID, "device %d out of range (have %d)", devices[i], ndev);
+    rayhs_multi *m = new rayhs_multi();
+    const size_t n = (size_t)n_devices;
+    m->devices.assign(devices, devices + n_devices);
+    m->scenes.assign(n, nullptr); m->streams.assign(n, nullptr); m->e0.assign(n, nullptr); m->e1.assign(n, nullptr); m->done.assign(n, nullptr);
+    m->out_dev.assign(n, nullptr); m->out_bytes.assign(n, 0); m->map_dev.assign(n, nullptr); m->map_cap.assign(n, 0); m->counters.assign(n, nullptr);
+    m->lists.assign(n, StripeList()); m->est_share.assign(n, 0.0);
+    auto fail = [&](int code) { rayhs_multi_destroy(m); return code; };
+    for (size_t i = 0; i < n; i++) {
+        // the same device may be listed more than once (a one-GPU rehearsal of the N-GPU path): every entry gets its own
+        // scene copy, stream and buffers, exactly as N different GPUs would
+        int rc = rayhs_scene_create(desc, devices[i], &m->scenes[i]);
+        if (rc) return fail(rc);
+        if (hipStreamCreateWithFlags(&m->streams[i], hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->e0[i]) != hipSuccess ||
+            hipEventCreate(&m->e1[i]) != hipSuccess || hipEventCreateWithFlags(&m->done[i], hipEventDisableTiming) != hipSuccess)
+            return fail(set_error(RAYHS_ERR_HIP, "stream / event creation failed on device %d", devices[i]));
+        void *p = nullptr;
+        if (hipMalloc(&p, sizeof(unsigned long long) * CNT_SLOTS_DEV) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(counters) failed"));
+        m->counters[i] = (unsigned long long *)p;
+        if (devices[i] != devices[0]) {  // this device will write its stripes into the frame on devices[0]
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) != hipSuccess || !can)
+                return fail(set_error(RAYHS_ERR_UNSUPPORTED, "device %d has no peer access to device %d", devices[i], devices[0]));
+            hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(set_error(RAYHS_ERR_HIP, "hipDeviceEnablePeerAccess failed: %s", hipGetErrorString(e)));
+            (void)hipGetLastError();
+        }
+    }
+    *out = m;
+    return RAYHS_OK;
+}
+
+extern "C" int rayhs_multi_device_count(const rayhs_multi *m) { return m ? (int)m->devices.size() : 0; }
+
+// Stripe lists for this frame geometry and camera: static estimate of the whole frame on devices[0] -> cost per stripe
+// -> longest-processing-time-first assignment -> one ascending list per device, uploaded.  Once per geometry / camera.
+static int plan_stripes(rayhs_multi *m, const rayhs_camera *cam, const rayhs_render_params *p) {
+    std::vector<unsigned char> key(sizeof(rayhs_camera) + 8 * sizeof(int));
+    std::memcpy(key.data(), cam, sizeof(rayhs_camera));
+    const int geo[8] = {p->width, p->height, p->row0, p->row1, p->stripe_rows, p->spp, p->max_depth, (int)(p->flags & RAYHS_FLAG_FMA)};
+    std::memcpy(key.data() + sizeof(rayhs_camera), geo, sizeof geo);
+    if (key == m->plan_key) return RAYHS_OK;
+    const size_t n = m->devices.size();
+    const int total = p->row1 - p->row0, R = p->stripe_rows, n_stripes = (total + R - 1) / R;
+    std::vector<double> stripe_cost((size_t)n_stripes, 1.0);
+    if (n > 1 && total > 0 && !std::getenv("RAYHS_ROUND_ROBIN_STRIPES")) {
+        rayhs_render_params whole = *p;
+        whole.stripe_rows = std::max(total, 1); whole.stripe_rank = 0; whole.stripe_count = 1; whole.flags &= RAYHS_FLAG_FMA;
+        DCamera dc; DParams dp; int variant, grid; bool exact; size_t lds;
+        int rc = prepare_launch(m->scenes[0], cam, &whole, nullptr, dc, dp, variant, exact, grid, lds);
+        if (rc) return rc;
+        HIP_TRY(hipSetDevice(m->devices[0]));
+        if ((size_t)dp.n_tiles > m->cost_cap) {
+            if (m->cost0) HIP_TRY(hipFree(m->cost0));
+            m->cost0 = nullptr; m->cost_cap = 0;
+            void *q = nullptr;
+            HIP_TRY(hipMalloc(&q, (size_t)dp.n_tiles * sizeof(float)));
+            m->cost0 = (float *)q; m->cost_cap = (size_t)dp.n_tiles;
+        }
+        hipError_t e = exact ? launch_static_costs_exact(m->streams[0], m->scenes[0]->d, dc, dp, m->cost0) : launch_static_costs_fast(m->streams[0], m->scenes[0]->d, dc, dp, m->cost0);
+        if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "static cost launch failed: %s", hipGetErrorString(e));
+        std::vector<float> tile_cost((size_t)dp.n_tiles);
+        HIP_TRY(hipMemcpyAsync(tile_cost.data(), m->cost0, tile_cost.size() * sizeof(float), hipMemcpyDeviceToHost, m->streams[0]));
+        HIP_TRY(hipStreamSynchronize(m->streams[0]));
+        const int tile_rows = (total + 7) / 8;
+        std::vector<double> row_cost((size_t)tile_rows, 0.0);
+        for (int ty = 0; ty < tile_rows; ty++)
+            for (int tx = 0; tx < dp.tiles_x; tx++) row_cost[(size_t)ty] += tile_cost[(size_t)ty * (size_t)dp.tiles_x + (size_t)tx];
+        for (int st = 0; st < n_stripes; st++) {  // a stripe gets the tile rows it overlaps, by overlap
+            const int a = st * R, b = std::min(total, a + R);
+            double c = 0;
+            for (int ty = a / 8; ty <= (b - 1) / 8; ty++) {
+                const int lo = std::max(a, ty * 8), hi = std::min(b, ty * 8 + 8);
+                c += row_cost[(size_t)ty] * (double)(hi - lo) / 8.0;
+            }
+            stripe_cost[(size_t)st] = c;
+        }
+    }
+    // longest processing time first; ties and the round-robin fallback keep the interleaved pattern
+    std::vector<int> by_cost((size_t)n_stripes);
+    for (int i = 0; i < n_stripes; i++) by_cost[(size_t)i] = i;
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return stripe_cost[(size_t)a] > stripe_cost[(size_t)b]; });
+    std::vector<std::vector<int32_t>> lists(n);
+    std::vector<double> load(n, 0.0);
+    const bool round_robin = n == 1 || std::getenv("RAYHS_ROUND_ROBIN_STRIPES");
+    for (int k = 0; k < n_stripes; k++) {
+        const int st = round_robin ? k : by_cost[(size_t)k];
+        size_t best = 0;
+        if (round_robin) best = (size_t)k % n;
+        else
+            for (size_t i = 1; i < n; i++)
+                if (load[i] < load[best]) best = i;
+        lists[best].push_back(st);
+        load[best] += stripe_cost[(size_t)st];
+    }
+    double sum = 0;
+    for (double v : load) sum += v;
+    for (size_t i = 0; i < n; i++) {
+        std::sort(lists[i].begin(), lists[i].end());
+        m->est_share[i] = sum > 0 ? load[i] / sum : 0.0;
+        StripeList &sl = m->lists[i];
+        sl.n_stripes = (int)lists[i].size();
+        sl.rows = 0;
+        for (int st : lists[i]) sl.rows += std::min(R, total - st * R);
+        sl.id = m->next_list_id++;
+        HIP_TRY(hipSetDevice(m->devices[i]));
+        if (lists[i].size() > m->map_cap[i]) {
+            if (m->map_dev[i]) HIP_TRY(hipFree(m->map_dev[i]));
+            m->map_dev[i] = nullptr; m->map_cap[i] = 0;
+            void *q = nullptr;
+            HIP_TRY(hipMalloc(&q, lists[i].size() * sizeof(int32_t)));
+            m->map_dev[i] = (int32_t *)q; m->map_cap[i] = lists[i].size();
+        }
+        if (!lists[i].empty()) {
+            HIP_TRY(hipStreamSynchronize(m->streams[i]));  // a previous frame may still read the old list
+            HIP_TRY(hipMemcpy(m->map_dev[i], lists[i].data(), lists[i].size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        sl.d_map = m->map_dev[i];
+    }
+    m->plan_key = key;
+    return RAYHS_OK;
+}
+
+// shares[i] = estimated fraction of the frame's cost given to device i by the last plan (diagnostics / tests)
+extern "C" int rayhs_multi_shares(const rayhs_multi *m, double *shares, int *rows, int n) {
+    if (!m || n < (int)m->devices.size()) return set_error(RAYHS_ERR_INVALID, "bad argument");
+    for (size_t i = 0; i < m->devices.size(); i++) {
+        if (shares) shares[i] = m->est_share[i];
+        if (rows) rows[i] = m->lists[i].rows;
+    }
+    return RAYHS_OK;
+}
+
+static int multi_render(rayhs_multi *m, const rayhs_camera *cam, const rayhs_render_params *p_in, void *out_host, void *d_out, rayhs_stats *stats) {
+    if (!m || !cam || !p_in || (!out_host && !d_out)) return set_error(RAYHS_ERR_INVALID, "NULL argument");
+    rayhs_render_params p = *p_in;
+    if (p.stripe_rows < 1) p.stripe_rows = 8;
+    p.stripe_rank = 0; p.stripe_count = 1;  // ownership is the library's here
+    if (p.width <= 0 || p.height <= 0 || p.row0 < 0 || p.row1 < p.row0 || p.row1 > p.height) return set_error(RAYHS_ERR_INVALID, "bad width/height/row range");
+    if (p.out_format < RAYHS_OUT_F32 || p.out_format > RAYHS_OUT_I16) return set_error(RAYHS_ERR_INVALID, "bad out_format");
+    if (p.flags & RAYHS_FLAG_EXHAUSTIVE && !(p.flags & RAYHS_FLAG_COUNT)) return set_error(RAYHS_ERR_INVALID, "RAYHS_FLAG_EXHAUSTIVE needs RAYHS_FLAG_COUNT");
+    const size_t n = m->devices.size();
+    const int total = p.row1 - p.row0;
+    const size_t esz = p.out_format == RAYHS_OUT_F64 ? 8 : p.out_format == RAYHS_OUT_F32 ? 4 : 2;
+    const size_t row_bytes = (size_t)p.width * 3 * esz, bytes = row_bytes * (size_t)total;
+    int rc = plan_stripes(m, cam, &p);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    void *frame = d_out;
+    if (!frame) {
+        if (bytes > m->frame_bytes || !m->frame) {
+            if (m->frame) HIP_TRY(hipFree(m->frame));
+            m->frame = nullptr; m->frame_bytes = 0;
+            HIP_TRY(hipMalloc(&m->frame, std::max<size_t>(bytes, 16)));
+            m->frame_bytes = std::max<size_t>(bytes, 16);
+        }
+        frame = m->frame;
+    }
+    const bool count = (p.flags & RAYHS_FLAG_COUNT) != 0, exact = (p.flags & RAYHS_FLAG_FMA) == 0;
+    for (size_t i = 0; i < n; i++) {
+        const StripeList &sl = m->lists[i];
+        HIP_TRY(hipSetDevice(m->devices[i]));
+        if (count) HIP_TRY(hipMemsetAsync(m->counters[i], 0, sizeof(unsigned long long) * CNT_SLOTS_DEV, m->streams[i]));
+        const size_t need = row_bytes * (size_t)sl.rows;
+        if (need > m->out_bytes[i] || !m->out_dev[i]) {
+            if (m->out_dev[i]) { HIP_TRY(hipStreamSynchronize(m->streams[i])); HIP_TRY(hipFree(m->out_dev[i])); }
+            m->out_dev[i] = nullptr; m->out_bytes[i] = 0;
+            HIP_TRY(hipMalloc(&m->out_dev[i], std::max<size_t>(need, 16)));
+            m->out_bytes[i] = std::max<size_t>(need, 16);
+        }
+        rc = launch(m->scenes[i], cam, &p, m->out_dev[i], m->streams[i], count ? (uint64_t *)m->counters[i] : nullptr, m->e0[i], m->e1[i], &sl);
+        if (rc) return rc;
+        // push the finished stripes to their rows of the frame on devices[0] (peer write over xGMI)
+        hipError_t e = exact ? launch_scatter_stripes_exact(m->streams[i], m->out_dev[i], frame, sl.d_map, sl.rows, p.stripe_rows, (long long)row_bytes)
+                             : launch_scatter_stripes_fast(m->streams[i], m->out_dev[i], frame, sl.d_map, sl.rows, p.stripe_rows, (long long)row_bytes);
+        if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "stripe scatter launch failed: %s", hipGetErrorString(e));
+        HIP_TRY(hipEventRecord(m->done[i], m->streams[i]));
+    }
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    for (size_t i = 1; i < n; i++) HIP_TRY(hipStreamWaitEvent(m->streams[0], m->done[i], 0));
+    if (out_host && bytes) HIP_TRY(hipMemcpyAsync(out_host, frame, bytes, hipMemcpyDeviceToHost, m->streams[0]));
+    HIP_TRY(hipStreamSynchronize(m->streams[0]));
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        for (size_t i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(m->devices[i]));
+            HIP_TRY(hipStreamSynchronize(m->streams[i]));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, m->e0[i], m->e1[i]));
+            stats->kernel_ms = std::max(stats->kernel_ms, (double)ms);  // the slowest device's trace kernel
+            if (count) {
+                unsigned long long c[CNT_SLOTS_DEV];
+                HIP_TRY(hipMemcpy(c, m->counters[i], sizeof c, hipMemcpyDeviceToHost));
+                stats->rays_primary += c[CNT_PRIMARY]; stats->rays_reflect += c[CNT_REFLECT]; stats->rays_refract += c[CNT_REFRACT];
+                stats->rays_refract_exit += c[CNT_REFRACT_EXIT]; stats->rays_shadow += c[CNT_SHADOW];
+                stats->nodes_tested += c[CNT_NODES]; stats->tris_tested += c[CNT_TRIS]; stats->prims_tested += c[CNT_PRIMS];
+                stats->shadow_skipped += c[CNT_SHADOW_SKIPPED];
+                stats->shaded_hits += c[CNT_SHADED]; stats->pixels += c[CNT_PIXELS] / (unsigned long long)std::max(p.spp, 1);
+            }
+        }
+        HIP_TRY(hipSetDevice(m->devices[0]));
+    }
+    return RAYHS_OK;
+}
+
+extern "C" int rayhs_multi_render(rayhs_multi *m, const rayhs_camera *cam, const rayhs_render_params *p, void *out_host, rayhs_stats *stats) {
+    if (!out_host) return set_error(RAYHS_ERR_INVALID, "out_host is NULL");
+    return multi_render(m, cam, p, out_host, nullptr, stats);
+}
+extern "C" int rayhs_multi_render_device(rayhs_multi *m, const rayhs_camera *cam, const rayhs_render_params *p, void *d_out, rayhs_stats *stats) {
+    if (!d_out) return set_error(RAYHS_ERR_INVALID, "d_out is NULL");
+    return multi_render(m, cam, p, nullptr, d_out, stats);
 }
 
 // ----------------------------------------------------------------- host prep

@@ -8,6 +8,8 @@
 // more arguments follow.  Extra long options that the reference lacks:
 //   --spp=N --seed=S   multi-sample path (distributedTracePixel semantics)
 //   --device=N         HIP device (default 0)
+//   --gpus=N           trace the frame on GPUs 0..N-1 of this node (stripes per GPU, assembled on GPU 0)
+//   --devices=a,b,...  the same with an explicit device list (a device may repeat: one-GPU rehearsal)
 //   --stats            work counters and kernel time on stderr
 //   --timing           wall time of each stage (load, upload, render, write) on stderr
 // The trace runs on the GPU through the C ABI; there is no CPU path.
@@ -34,6 +36,7 @@ int main(int argc, char **argv) {
     std::string out_file = "out.ppm";
     bool have_output_flag = false;
     int spp = 1, device = 0;
+    std::vector<int> devices;  // non-empty: the multi-GPU path
     unsigned long long seed = 24;  // src/RayHs.hs:239
     bool want_stats = false, want_timing = false;
     std::vector<std::string> errors;
@@ -61,6 +64,20 @@ int main(int argc, char **argv) {
         } else if (long_opt("spp")) { spp = has_val ? std::atoi(val.c_str()) : 1; }
         else if (long_opt("seed")) { seed = has_val ? std::strtoull(val.c_str(), nullptr, 10) : 24; }
         else if (long_opt("device")) { device = has_val ? std::atoi(val.c_str()) : 0; }
+        else if (long_opt("gpus")) {
+            const int n = has_val ? std::atoi(val.c_str()) : 1;
+            if (n < 1 || n > 64) errors.push_back("option `--gpus' needs a count between 1 and 64\n");
+            else { devices.clear(); for (int d = 0; d < n; d++) devices.push_back(d); }
+        } else if (long_opt("devices")) {
+            devices.clear();
+            for (size_t a0 = 0; has_val && a0 <= val.size();) {
+                size_t b0 = val.find(',', a0);
+                if (b0 == std::string::npos) b0 = val.size();
+                if (b0 > a0) devices.push_back(std::atoi(val.substr(a0, b0 - a0).c_str()));
+                a0 = b0 + 1;
+            }
+            if (devices.empty()) errors.push_back("option `--devices' needs a comma-separated device list\n");
+        }
         else if (long_opt("stats")) { want_stats = true; }
         else if (long_opt("timing")) { want_timing = true; }
         else errors.push_back("unrecognized option `" + a + "'\n");
@@ -94,7 +111,10 @@ int main(int argc, char **argv) {
     ms_load = ms_since(t_start);
     clk::time_point t0 = clk::now();
     rayhs_scene *scene = nullptr;
-    if (rayhs_scene_create(rayhs_render_desc_scene(rd), device, &scene) != RAYHS_OK) die(rayhs_last_error());
+    rayhs_multi *multi = nullptr;
+    if (devices.empty()) {
+        if (rayhs_scene_create(rayhs_render_desc_scene(rd), device, &scene) != RAYHS_OK) die(rayhs_last_error());
+    } else if (rayhs_multi_create(rayhs_render_desc_scene(rd), devices.data(), (int)devices.size(), &multi) != RAYHS_OK) die(rayhs_last_error());
     ms_upload = ms_since(t0);
     rayhs_render_params p;
     std::memset(&p, 0, sizeof p);
@@ -105,7 +125,7 @@ int main(int argc, char **argv) {
     p.seed = seed;
     p.row0 = 0;
     p.row1 = p.height;
-    p.stripe_rows = p.height > 0 ? p.height : 1;
+    p.stripe_rows = multi ? 8 : (p.height > 0 ? p.height : 1);
     p.stripe_rank = 0;
     p.stripe_count = 1;
     p.out_format = RAYHS_OUT_I16;
@@ -121,7 +141,8 @@ int main(int argc, char **argv) {
         std::vector<int16_t> q((size_t)p.width * (size_t)p.height * 3);
         rayhs_stats st;
         t0 = clk::now();
-        if (rayhs_render(scene, rayhs_render_desc_camera(rd), &p, q.data(), &st) != RAYHS_OK) die(rayhs_last_error());
+        if ((multi ? rayhs_multi_render(multi, rayhs_render_desc_camera(rd), &p, q.data(), &st)
+                   : rayhs_render(scene, rayhs_render_desc_camera(rd), &p, q.data(), &st)) != RAYHS_OK) die(rayhs_last_error());
         ms_render = ms_since(t0);
         ms_kernel = st.kernel_ms;  // the trace kernel of this one frame: a first frame, ordered by the static tile estimate
         t0 = clk::now();
@@ -140,6 +161,7 @@ int main(int argc, char **argv) {
         }
     }
     rayhs_scene_destroy(scene);
+    rayhs_multi_destroy(multi);
     rayhs_render_desc_free(rd);
     if (want_timing)
         std::fprintf(stderr, "{\"load_ms\": %.1f, \"scene_create_ms\": %.1f, \"render_ms\": %.1f, \"first_frame_kernel_ms\": %.3f, \"write_ms\": %.1f, \"total_ms\": %.1f}\n",

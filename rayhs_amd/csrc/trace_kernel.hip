@@ -47,6 +47,8 @@
 // experiments; the defaults are the measured optimum).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_scene.h"
 
 #ifndef RAYHS_REFILL_MIN
@@ -871,11 +873,13 @@ static __device__ __forceinline__ void trace_body() {
                 item_valid = px < prm.width && lrow < prm.n_rows;
                 if (item_valid) {
                     // local row -> image row (stripe interleave, include/rayhs.h)
-                    if (prm.stripe_count == 1) yrow = prm.row0 + lrow;
+                    if (prm.stripe_count == 1 && prm.stripe_map == nullptr) yrow = prm.row0 + lrow;
                     else {
                         const int s_local = prm.stripe_shift >= 0 ? lrow >> prm.stripe_shift : lrow / prm.stripe_rows;
                         const int in_stripe = lrow - s_local * prm.stripe_rows;
-                        yrow = prm.row0 + (s_local * prm.stripe_count + prm.stripe_rank) * prm.stripe_rows + in_stripe;
+                        // round-robin ownership, or an explicit list of this device's stripes (rayhs_multi: cost-balanced)
+                        const int s_global = prm.stripe_map ? prm.stripe_map[s_local] : s_local * prm.stripe_count + prm.stripe_rank;
+                        yrow = prm.row0 + s_global * prm.stripe_rows + in_stripe;
                     }
                     state = ST_NEW_SAMPLE;
                 }
@@ -1286,9 +1290,10 @@ RAYHS_CAT(rayhs_static_costs, RAYHS_KERNEL_SUFFIX)(DScene sc, DCamera cam, DPara
     if (tile >= prm.n_tiles) return;
     const int ty = tile / prm.tiles_x, tx = tile - ty * prm.tiles_x;
     auto image_row = [&](int lrow) {  // local row -> image row (stripe interleave, as in the trace kernel)
-        if (prm.stripe_count == 1) return prm.row0 + lrow;
+        if (prm.stripe_count == 1 && prm.stripe_map == nullptr) return prm.row0 + lrow;
         const int s_local = lrow / prm.stripe_rows, in_stripe = lrow - s_local * prm.stripe_rows;
-        return prm.row0 + (s_local * prm.stripe_count + prm.stripe_rank) * prm.stripe_rows + in_stripe;
+        const int s_global = prm.stripe_map ? prm.stripe_map[s_local] : s_local * prm.stripe_count + prm.stripe_rank;
+        return prm.row0 + s_global * prm.stripe_rows + in_stripe;
     };
     const int x0 = tx * 8, x1 = min(x0 + 8, prm.width), l0 = ty * 8, l1 = min(l0 + 8, prm.n_rows);
     const double ytop = (double)image_row(l0), ybot = (double)image_row(l1 - 1) + 1.0;
@@ -1355,6 +1360,27 @@ RAYHS_DEFINE_KERNEL(rayhs_trace_count, false, true, unsigned int, 2)
 #endif
 RAYHS_DEFINE_KERNEL(rayhs_trace_exh_count, true, true, unsigned int, 1)
 
+// rayhs_multi: a device's finished stripes (compact, in the order of its stripe list) go to their rows of the whole
+// frame, which lives on the first device -- a peer WRITE over xGMI when the two are different GPUs.  HBM / link bound:
+// every byte is read once and written once, in units of `unit` bytes (16 when the row size allows it).
+extern "C" __global__ void __launch_bounds__(256)
+RAYHS_CAT(rayhs_scatter_stripes, RAYHS_KERNEL_SUFFIX)(const char *src, char *dst, const int *stripe_map, int n_rows, int stripe_rows,
+                                                      long long row_bytes, int unit) {
+    const long long units_per_row = row_bytes / unit, total = units_per_row * (long long)n_rows;
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long long)gridDim.x * 256) {
+        const int lrow = (int)(k / units_per_row);
+        const long long in_row = (k - (long long)lrow * units_per_row) * unit;
+        const int s_local = lrow / stripe_rows, in_stripe = lrow - s_local * stripe_rows;
+        const long long drow = (long long)stripe_map[s_local] * stripe_rows + in_stripe;
+        const char *a = src + (long long)lrow * row_bytes + in_row;
+        char *b = dst + drow * row_bytes + in_row;
+        if (unit == 16) *(uint4 *)b = *(const uint4 *)a;
+        else if (unit == 8) *(uint2 *)b = *(const uint2 *)a;
+        else if (unit == 4) *(unsigned *)b = *(const unsigned *)a;
+        else *(unsigned short *)b = *(const unsigned short *)a;
+    }
+}
+
 // Host-side launcher of this translation unit's kernels (called from abi.cpp).
 namespace rayhs {
 static const void *RAYHS_CAT(kernel_ptr, RAYHS_KERNEL_SUFFIX)(int variant) {
@@ -1379,6 +1405,18 @@ hipError_t RAYHS_CAT(launch_resolve, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, co
 }
 hipError_t RAYHS_CAT(launch_static_costs, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, const DScene &sc, const DCamera &cam, const DParams &prm, float *cost) {
     hipLaunchKernelGGL(RAYHS_CAT(rayhs_static_costs, RAYHS_KERNEL_SUFFIX), dim3((unsigned)((prm.n_tiles + 255) / 256)), dim3(256), 0, stream, sc, cam, prm, cost);
+    return hipGetLastError();
+}
+hipError_t RAYHS_CAT(launch_scatter_stripes, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, const void *src, void *dst, const int *stripe_map, int n_rows,
+                                                               int stripe_rows, long long row_bytes) {
+    if (n_rows <= 0 || row_bytes <= 0) return hipSuccess;
+    int unit = 2;
+    for (int u : {16, 8, 4})
+        if (row_bytes % u == 0 && (unsigned long long)src % (unsigned)u == 0 && (unsigned long long)dst % (unsigned)u == 0) { unit = u; break; }
+    const long long total = row_bytes / unit * (long long)n_rows;
+    const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(RAYHS_CAT(rayhs_scatter_stripes, RAYHS_KERNEL_SUFFIX), dim3(grid), dim3(256), 0, stream, (const char *)src, (char *)dst, stripe_map,
+                       n_rows, stripe_rows, row_bytes, unit);
     return hipGetLastError();
 }
 hipError_t RAYHS_CAT(launch_order_tiles, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, float *cost, int n, int *order) {

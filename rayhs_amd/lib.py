@@ -81,6 +81,12 @@ SYMBOLS = [
     ("rayhs_render_device", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rayhs_render_device_events", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p]),
+    ("rayhs_multi_create", C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    ("rayhs_multi_destroy", None, [C.c_void_p]),
+    ("rayhs_multi_device_count", C.c_int, [C.c_void_p]),
+    ("rayhs_multi_render", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),
+    ("rayhs_multi_render_device", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),
+    ("rayhs_multi_shares", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
     ("rayhs_render_desc_load", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     ("rayhs_render_desc_parse", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     ("rayhs_render_desc_free", None, [C.c_void_p]),

@@ -314,6 +314,59 @@ def test_empty_row_selection_records_the_callers_events():
     r.close()
 
 
+# --------------------------------------- several GPUs from one process (rayhs_multi)
+def test_multi_device_frame_equals_the_single_device_frame_one_gpu_rehearsal():
+    # the N-GPU path of the library (stripe lists balanced by the static estimate, per-device streams, peer push into
+    # the frame on the first device) with every "device" being GPU 0 -- what the driver's 8-GPU node runs with 8 GPUs
+    rd = RenderDesc("scenes/dragon_low_1080p.json")
+    single = Rendering(rd)
+    for fmt in (L.OUT_F32, L.OUT_I16):
+        want, _ = single.ray_trace(spp=4, out_format=fmt)
+        for devices in ([0, 0, 0], [0] * 8):
+            m = rayhs_amd.MultiRendering(rd, devices)
+            for _ in range(2):                               # first frame (static tile order), then the measured order
+                got, st = m.ray_trace(spp=4, out_format=fmt)
+                assert np.array_equal(got, want), (fmt, devices)
+            shares, rows = m.shares()
+            assert sum(rows) == rd.height and abs(sum(shares) - 1) < 1e-9
+            assert max(shares) / (1.0 / len(devices)) < 1.08, shares      # cost-balanced: no device above 108 % of its fair share
+            m.close()
+    _assert_frame_matches_digest(single.ray_trace(spp=4, out_format=L.OUT_F32)[0], "dragon_low")
+    single.close()
+
+
+@pytest.mark.parametrize("w,h,stripe,devices", [(77, 53, 5, [0, 0]), (64, 20, 8, [0] * 5), (33, 7, 8, [0, 0, 0]), (96, 96, 16, [0])])
+def test_multi_device_ragged_frames_row_ranges_and_counters(w, h, stripe, devices):
+    rd = RenderDesc("scenes/dragon_superlow_96.json")
+    single = Rendering(rd, width=w, height=h)
+    m = rayhs_amd.MultiRendering(rd, devices, width=w, height=h)
+    want, st1 = single.ray_trace(spp=2, flags=COUNTING)
+    got, st = m.ray_trace(spp=2, stripe_rows=stripe, flags=COUNTING)
+    assert np.array_equal(got, want)
+    for k in ("rays", "rays_shadow", "shaded_hits", "pixels", "shadow_skipped"):
+        assert st[k] == st1[k], k
+    got, _ = m.ray_trace(spp=2, stripe_rows=stripe)              # the production kernels
+    assert np.array_equal(got, want)
+    if h > 12:
+        part, _ = m.ray_trace(spp=2, stripe_rows=stripe, row0=3, row1=h - 4)
+        assert np.array_equal(part, want[3:h - 4])
+    m.close()
+    single.close()
+
+
+def test_cli_gpus_option_writes_the_same_file(tmp_path):
+    a, b = tmp_path / "one.ppm", tmp_path / "multi.ppm"
+    r = rayhs_amd.run_cli([f"-o{a}", "--spp=2", "scenes/dragon_superlow_96.json"], cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    r = rayhs_amd.run_cli([f"-o{b}", "--spp=2", "--devices=0,0,0", "scenes/dragon_superlow_96.json"], cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    assert a.read_bytes() == b.read_bytes()
+    r = rayhs_amd.run_cli([f"-o{b}", "--gpus=1", "scenes/cornell_96.json"], cwd=ROOT)
+    assert r.returncode == 0 and b.read_bytes().startswith(b"P3\n96 96\n255\n")
+    r = rayhs_amd.run_cli([f"-o{b}", "--gpus=99", "scenes/cornell_96.json"], cwd=ROOT)
+    assert r.returncode == 1 and "--gpus" in r.stderr
+
+
 # ------------------------------------------------- BASELINE sizes: properties
 @pytest.mark.parametrize("scene,spp", [("scenes/cornell_1080p_d0.json", 1), ("scenes/dragon_low_1080p.json", 4)])
 def test_full_size_properties(scene, spp):

@@ -278,6 +278,21 @@ def test_compute_entry_points_refuse_without_gpu():
     assert r.returncode == 1 and "no HIP device" in r.stderr and not os.path.exists("/tmp/_x.ppm")
 
 
+def test_multi_device_entry_validates_its_arguments_and_refuses_without_gpu():
+    rd = RenderDesc("scenes/cornell_96.json")
+    h = C.c_void_p()
+    lib = L.load()
+    assert lib.rayhs_multi_create(C.byref(rd.scene_desc), None, 2, C.byref(h)) == L.ERR_INVALID
+    assert lib.rayhs_multi_create(C.byref(rd.scene_desc), (C.c_int * 1)(0), 0, C.byref(h)) == L.ERR_INVALID
+    rc = lib.rayhs_multi_create(C.byref(rd.scene_desc), (C.c_int * 2)(0, 99), 2, C.byref(h))
+    assert rc == (L.ERR_INVALID if HAVE_GPU else L.ERR_NO_DEVICE) and not h.value
+    assert lib.rayhs_multi_device_count(None) == 0
+    lib.rayhs_multi_destroy(None)                            # like free(NULL)
+    if not HAVE_GPU:
+        r = rayhs_amd.run_cli(["-o/tmp/_x.ppm", "--gpus=2", "scenes/cornell_96.json"], cwd=ROOT)
+        assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
 def test_scene_desc_validation_rejects_broken_trees():
     rd = RenderDesc("scenes/cornell_96.json")
     d = rd.scene_desc
