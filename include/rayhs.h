@@ -236,8 +236,9 @@ int rayhs_multi_render(rayhs_multi *multi, const rayhs_camera *camera, const ray
 /* Same into a DEVICE buffer that lives on devices[0]; synchronous. */
 int rayhs_multi_render_device(rayhs_multi *multi, const rayhs_camera *camera, const rayhs_render_params *params,
                               void *d_out, rayhs_stats *stats);
-/* After a render: the estimated share of the frame's cost (0..1) and the rows given to each device. Either may be NULL. */
-int rayhs_multi_shares(const rayhs_multi *multi, double *shares, int *rows, int n);
+/* After a render: per device the estimated share of the frame's cost (0..1), the rows it was given and (if that render
+ * asked for stats) its trace-kernel time.  Each array holds n >= device count entries or is NULL. */
+int rayhs_multi_shares(const rayhs_multi *multi, double *shares, int *rows, double *kernel_ms, int n);
 
 /* ---- host preparation (C++ restatement of the reference's L3/L4 host code;
  * the Haskell host would do this itself and call rayhs_scene_create) -------- */

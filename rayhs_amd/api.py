@@ -175,8 +175,15 @@ class MultiRendering:
     def shares(self):
         n = len(self.devices)
         sh, rows = (C.c_double * n)(), (C.c_int * n)()
-        L.check(L.load().rayhs_multi_shares(self._h, sh, rows, n))
+        L.check(L.load().rayhs_multi_shares(self._h, sh, rows, None, n))
         return list(sh), list(rows)
+
+    def kernel_ms(self):
+        """Trace-kernel time of every device in the last frame (rendered through ray_trace, which asks for stats)."""
+        n = len(self.devices)
+        ms = (C.c_double * n)()
+        L.check(L.load().rayhs_multi_shares(self._h, None, None, ms, n))
+        return list(ms)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -86,7 +86,7 @@ SYMBOLS = [
     ("rayhs_multi_device_count", C.c_int, [C.c_void_p]),
     ("rayhs_multi_render", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),
     ("rayhs_multi_render_device", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),
-    ("rayhs_multi_shares", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
+    ("rayhs_multi_shares", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]),
     ("rayhs_render_desc_load", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     ("rayhs_render_desc_parse", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     ("rayhs_render_desc_free", None, [C.c_void_p]),

@@ -315,7 +315,10 @@ def test_empty_row_selection_records_the_callers_events():
 
 
 # --------------------------------------- several GPUs from one process (rayhs_multi)
-def test_multi_device_frame_equals_the_single_device_frame_one_gpu_rehearsal():
+@pytest.mark.parametrize("policy", ["default", "RAYHS_LPT_STRIPES", "RAYHS_ROUND_ROBIN_STRIPES"])
+def test_multi_device_frame_equals_the_single_device_frame_one_gpu_rehearsal(policy, monkeypatch):
+    if policy != "default":
+        monkeypatch.setenv(policy, "1")      # development switches: force the cost-sorted / the interleaved ownership
     # the N-GPU path of the library (stripe lists balanced by the static estimate, per-device streams, peer push into
     # the frame on the first device) with every "device" being GPU 0 -- what the driver's 8-GPU node runs with 8 GPUs
     rd = RenderDesc("scenes/dragon_low_1080p.json")

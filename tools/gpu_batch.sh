@@ -11,6 +11,7 @@ for what in "$@"; do
     bench) timeout -k 10 300 python bench.py --steps 20 --warmup 3 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc=$?"; cat gpurun_out/${tag}_bench.json; tail -3 gpurun_out/${tag}_bench.err;;
     ptime) RAYHS_LIB=$PWD/build_exp/binpt/librayhs_hip.so RAYHS_DEBUG_COUNTERS=1 timeout -k 10 200 python tools/kbench.py dragon 3 > gpurun_out/${tag}_ptime.log 2>&1; grep "rayhs adv" gpurun_out/${tag}_ptime.log | tail -1;;
     ploops) RAYHS_LIB=$PWD/build_exp/binpl/librayhs_hip.so RAYHS_DEBUG_COUNTERS=1 timeout -k 10 200 python tools/kbench.py dragon 3 > gpurun_out/${tag}_ploops.log 2>&1; grep "rayhs adv" gpurun_out/${tag}_ploops.log | tail -1;;
+    balance) timeout -k 10 800 python tools/stripe_balance.py dragon dragon_low dragon4k > gpurun_out/${tag}_stripe_balance.jsonl 2> gpurun_out/${tag}_stripe_balance.err; cat gpurun_out/${tag}_stripe_balance.jsonl; tail -3 gpurun_out/${tag}_stripe_balance.err;;
     firstframe) timeout -k 10 600 python tools/first_frame.py > gpurun_out/${tag}_first_frame.jsonl 2> gpurun_out/${tag}_first_frame.err; cat gpurun_out/${tag}_first_frame.jsonl; tail -3 gpurun_out/${tag}_first_frame.err;;
     default) for wl in dragon dragon_low cornell dragon4k; do timeout -k 10 200 python tools/kbench.py $wl 9 2>&1 | tail -1 | tee -a gpurun_out/${tag}_kbench.log; done;;
     *) for wl in dragon dragon_low cornell; do RAYHS_LIB=$PWD/build_exp/$what/librayhs_hip.so timeout -k 10 200 python tools/kbench.py $wl 9 2>&1 | tail -1 | tee -a gpurun_out/${tag}_kbench.log; done;;
