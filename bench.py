@@ -42,7 +42,9 @@ WORKLOADS = {
     "dragon4k": ("scenes/dragon_4k.json", 64, "dragon.obj in Cornell box 3840x2160, 64 spp, maxDepth 3 (BASELINE configs[4])"),
 }
 STRIPE_ROWS = 8
-IN_FLIGHT = int(os.environ.get("RAYHS_BENCH_IN_FLIGHT", "2"))  # frames enqueued at a time, each on its own scene handle and stream (see main)
+# frames enqueued at a time, each on its own scene handle and stream (see main): two when there is a gather to hide
+# behind the next frame's trace (N > 1), one on a single GPU (two buy nothing there and blur a profiler's per-kernel rows)
+IN_FLIGHT = int(os.environ.get("RAYHS_BENCH_IN_FLIGHT", "0")) or (2 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 1)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -50,24 +52,45 @@ def algorithmic_bytes(st):
     return (32 * st["nodes_tested"] + 36 * st["tris_tested"] + 40 * st["prims_tested"] + 60 * st["shaded_hits"] + 12 * st["pixels"])
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch of the trace kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE, separate runs, KiB -> bytes, read side doubled as MI355X_MICROARCH.md prescribes for
-    gfx950).  PMC counters cannot be read from inside this process, so the latest profiles/rNN/summary.json
-    of the same workload is used; None if there is none."""
+def kernel_source_sha256():
+    """Identity of the kernel being benchmarked: what tools/profile_round.sh records next to its counters."""
+    import hashlib
+    lines = []
+    for f in ("rayhs_amd/csrc/trace_kernel.hip", "rayhs_amd/csrc/device_scene.h", "rayhs_amd/csrc/abi.cpp"):
+        lines.append(f"{hashlib.sha256(open(os.path.join(ROOT, f), 'rb').read()).hexdigest()}  {f}\n")
+    return hashlib.sha256("".join(lines).encode()).hexdigest()
+
+
+def profile_counters(workload, kernel_ms):
+    """Counter-based figures of the trace kernel from the committed rocprofv3 PMC passes of this workload
+    (profiles/rNN/<workload>/summary.json; PMC counters cannot be read from inside this process).  They are used only
+    when that profile was taken on THIS kernel source (sha256 recorded by tools/profile_round.sh); otherwise every
+    counter-based field is null."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "summary.json"))):
-        try:
-            d = json.load(open(f))
-            if d.get("workload", "dragon") != workload:
-                continue
-            for k, v in d["pmc_mean_per_launch"].items():
-                if "count" not in k and "hbm_bytes_per_launch_read_doubled" in v:
-                    best = v["hbm_bytes_per_launch_read_doubled"]
-        except Exception:
-            pass
-    return best
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", workload, "summary.json")))
+    if not files:
+        return {"profile": None, "matches_this_kernel": False}, None
+    d = json.load(open(files[-1]))
+    src = {"profile": os.path.relpath(files[-1], ROOT), "kernel_source_sha256": d.get("kernel_source_sha256"),
+           "profile_kernel_ms": (d.get("timed_launches") or {}).get("avg_ms")}
+    src["matches_this_kernel"] = bool(src["kernel_source_sha256"]) and src["kernel_source_sha256"] == kernel_source_sha256()
+    c = next((v for k, v in d.get("pmc_mean_per_launch", {}).items() if "count" not in k), None)
+    if not src["matches_this_kernel"] or not c or "hbm_bytes_per_launch_read_doubled" not in c:
+        return src, None
+    waves = ((d.get("dispatch") or {}).get("launch") or {}).get("waves_per_simd", 4)
+    sec = kernel_ms * 1e-3
+    return src, {
+        "traffic": c["hbm_bytes_per_launch_read_doubled"],
+        "hbm_traffic_frac": c["hbm_bytes_per_launch_read_doubled"] / sec / 1e9 / HBM_PEAK_GBS,
+        "hbm_read_frac": 2 * c["hbm_read_bytes_raw"] / sec / 1e9 / HBM_PEAK_GBS,
+        "hbm_write_bytes": c["hbm_write_bytes"],
+        "l2_hit_rate": c.get("l2_hit_rate"),
+        "valu_busy": c["SQ_ACTIVE_INST_VALU_per_wave_cycle"] * waves if "SQ_ACTIVE_INST_VALU_per_wave_cycle" in c else None,
+        "valu_lane_util": c.get("valu_lane_utilisation"),
+        "wave_wait_frac": c.get("SQ_WAIT_ANY_per_wave_cycle"),
+        "salu_per_valu": c.get("salu_per_valu"),
+        "valu_insts_per_launch": c.get("SQ_INSTS_VALU"),
+    }
 
 
 def golden_digest(workload):
@@ -267,6 +290,19 @@ def main():
             raise SystemExit("bench.py: the rendered frame differs from the oracle's frame digest (tests/golden/frame_digests.json)")
         alg = algorithmic_bytes(mine)
         achieved = alg / (kernel_ms * 1e-3) / 1e9
+        # The contract line: algorithmic bytes per launch / kernel time against the HBM peak.  The scene is
+        # cache-resident, so `achieved` is served by L1 / scalar cache / L2 and can exceed the HBM peak: it is a work rate,
+        # not a bandwidth.  What binds the kernel is VALU issue; the counter-based fields next to it say how hard, and
+        # how little of the HBM bandwidth is really used.
+        src, ctr = profile_counters(args.workload, kernel_ms) if world == 1 else ({"profile": None, "matches_this_kernel": False}, None)
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": ctr["traffic"] if ctr else None, "algorithmic_bytes_per_launch": alg,
+                    "bound_actual": "valu-issue: the fp64 VALU pipe, not HBM -- the whole scene stays in cache; see valu_busy, valu_lane_util, hbm_traffic_frac",
+                    "hbm_traffic_frac": ctr and ctr["hbm_traffic_frac"], "hbm_read_frac": ctr and ctr["hbm_read_frac"],
+                    "hbm_write_bytes": ctr and ctr["hbm_write_bytes"], "l2_hit_rate": ctr and ctr["l2_hit_rate"],
+                    "valu_busy": ctr and ctr["valu_busy"], "valu_lane_util": ctr and ctr["valu_lane_util"],
+                    "wave_wait_frac": ctr and ctr["wave_wait_frac"], "salu_per_valu": ctr and ctr["salu_per_valu"],
+                    "valu_insts_per_launch": ctr and ctr["valu_insts_per_launch"], "counters_from": src}
         out = {
             "metric": "Mrays/s", "value": rays_frame * args.steps / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -281,11 +317,7 @@ def main():
             "kernel_ms_rank0": kernel_ms, "first_frame_ms": first_frame_ms,
             "verified_against_single_rank": verified,
             "verified_against_oracle": {"whole_frame_sha256_equals_oracle_digest": golden_ok, "rows_against_live_oracle": None},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.workload) if world == 1 else None,
-                         "algorithmic_bytes_per_launch": alg,
-                         "note": "traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/); the scene is "
-                                 "cache-resident, so it is far BELOW the algorithmic bytes and mostly workspace writes"},
+            "roofline": roofline,
         }
         if world == 1 and args.cpu_seconds > 0:
             threads = max(1, min(16, len(os.sched_getaffinity(0))))

@@ -1,19 +1,26 @@
 #!/bin/bash
-# Round evidence on the GPU box:  gpurun -- 'bash tools/profile_round.sh r01'
-# then, back home:                python tools/summarize_profiles.py r01 dragon
-# One bench line, the rocprofv3 --kernel-trace --stats summary of the same command, and four PMC passes
-# (counters in their own runs, no other trace domain -- see MI355X_MICROARCH.md, HBM/rocprofv3 section).
+# Round evidence on the GPU box:   gpurun -- 'bash tools/profile_round.sh r02 dragon'      (one workload per call)
+# then, back home:                 python tools/summarize_profiles.py r02 dragon
+# Per workload: one bench line, the rocprofv3 --kernel-trace --stats summary of the same command (ONE frame in flight,
+# one stream: the --stats rows of every kernel are then its real duration), and four PMC passes (counters in their own
+# runs, no other trace domain -- see MI355X_MICROARCH.md, HBM/rocprofv3 section).
 set -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
+wl=${2:-dragon}
 out=gpurun_out
+pre=$out/${tag}_${wl}
 export TMPDIR=/tmp
-rm -rf $out/${tag}_trace $out/${tag}_pmc_* $out/bench_${tag}.* $out/${tag}_trace_bench.json
+export RAYHS_BENCH_IN_FLIGHT=1
+rm -rf ${pre}_trace ${pre}_pmc_* ${pre}_bench.* ${pre}_trace_bench.json
 mkdir -p $out
-timeout -k 10 400 python3 bench.py --steps 30 --warmup 5 > $out/bench_${tag}.json 2> $out/bench_${tag}.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- python3 bench.py --steps 30 --warmup 5 --cpu-seconds 0 > $out/${tag}_trace_bench.json 2>/dev/null || exit 2
-pmc() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $out/${tag}_pmc_$name -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 > /dev/null 2>&1; }
+steps=30; [ "$wl" = dragon4k ] && steps=8
+sha256sum rayhs_amd/csrc/trace_kernel.hip rayhs_amd/csrc/device_scene.h rayhs_amd/csrc/abi.cpp | sha256sum | cut -d' ' -f1 > ${pre}_kernel_source.sha256
+timeout -k 10 500 python3 bench.py --workload $wl --steps $steps --warmup 3 > ${pre}_bench.json 2> ${pre}_bench.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d ${pre}_trace -- python3 bench.py --workload $wl --steps $steps --warmup 3 --cpu-seconds 0 > ${pre}_trace_bench.json 2>/dev/null || exit 2
+pmc() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d ${pre}_pmc_$name -- python3 bench.py --workload $wl --steps 3 --warmup 1 --cpu-seconds 0 > /dev/null 2>&1; }
 pmc fetch FETCH_SIZE || exit 3
 pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum || exit 4
 pmc sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU || exit 5
 pmc sq2 SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_FLAT GRBM_GUI_ACTIVE || exit 6
-cat $out/bench_${tag}.json
+RAYHS_DEBUG_COUNTERS=1 python3 tools/kbench.py $wl 1 2>&1 | grep "rayhs launch" | tail -1 > ${pre}_launch.txt
+cat ${pre}_bench.json
