@@ -43,22 +43,13 @@
 //     direction and the continuation frames of suspended irradiance calls live in a global workspace
 //     (slot-major so lanes coalesce).
 // Development switches: RAYHS_PROFILE_LOOPS / RAYHS_PROFILE_TIME (diagnostic builds with trip counters
-// or s_memtime stamps, read with RAYHS_DEBUG_COUNTERS=1), RAYHS_REFILL_MIN / RAYHS_CHUNK (scheduling
-// experiments; the defaults are the measured optimum).
+// or s_memtime stamps, read with RAYHS_DEBUG_COUNTERS=1).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 
 #include "device_scene.h"
 
-#ifndef RAYHS_REFILL_MIN
-#define RAYHS_REFILL_MIN 64 // idle lanes that trigger a refill.  64 = the wave refills as a whole: its 64 lanes then hold
-                            // consecutive samples of the same few pixels and stay in lock-step (measured: 11.3 ms
-                            // against 16.2 ms with per-lane refill on dragon.obj 1080p/16spp)
-#endif
-#ifndef RAYHS_CHUNK
-#define RAYHS_CHUNK 64      // work items drawn from the global ticket at a time
-#endif
 #ifndef RAYHS_KERNEL_SUFFIX
 #define RAYHS_KERNEL_SUFFIX fast
 #endif
@@ -701,7 +692,7 @@ struct Tracer {
 
 // ---- global per-lane workspace: LANE_SLOTS lane slots, then FRAME_SLOTS per continuation level ----
 enum : int { LS_V = 0, LS_TERM = 3 };
-enum : int { FS_KIND = 0 /* kind + 4 * depth */, FS_F = 2, FS_S = 3, FS_K = 4, FS_A = 5, FS_RO = 8, FS_RD = 11 };
+enum : int { FS_KIND = 0, FS_F = 2, FS_S = 3, FS_K = 4, FS_A = 5, FS_RO = 8, FS_RD = 11 };
 // slot-major: slot s of lane g sits at frames[s * stride + g]; addressed as uniform base + 32-bit byte offset
 struct Workspace { double *base; unsigned stride, lane; };
 DEV double *ws_at(const Workspace &ws, int slot) {
@@ -744,10 +735,11 @@ static __device__ __forceinline__ void trace_body() {
     Tracer<EXH, COUNT, StackT> tr(stk, cnt);
     const Workspace ws = {kargs()->frames, (unsigned)PRM.frame_stride, (unsigned)gtid};
 
-    // per-lane state that stays in registers across a scene query
+    // per-lane state that stays in registers across a scene query.  Which pixel and sample a lane works on is NOT
+    // among it: a wave always holds one whole chunk of 64 consecutive work items, lane i the i-th, so pixel, row and
+    // sample follow from the chunk's first item (SGPRs) and the lane number whenever they are needed (locate()).
     int state = ST_DONE;
-    int px = 0, lrow = 0, yrow = 0, sample = 0;
-    int depth = 0, fsp = 0;
+    int fsp = 0;  // suspended irradiance calls = recursion depth of the ray in flight (every frame pushed deepens it by one)
     Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
     int qkind = Q_NONE;
     bool q_point = false; double q_d2 = 0, q_dist = 0;
@@ -755,12 +747,12 @@ static __device__ __forceinline__ void trace_body() {
     bool occluded = false;
 
     // Work items are (pixel, sample) pairs: item / spp is a pixel slot in 8x8-tile order (slot >> 6 = tile,
-    // slot & 63 = Morton position in the tile), item % spp the sample.  A wave draws chunks of kChunk items from
-    // the global ticket into a wave-local pool and hands them to its idle lanes, so a lane that finishes a
-    // sample gets the next one at once.  (Per-pixel items left the frame waiting on single lanes that
-    // held an expensive pixel: 16 samples in sequence.)
-    constexpr unsigned kChunk = RAYHS_CHUNK;
-    unsigned long long pool_next = 0, pool_end = 0;
+    // slot & 63 = Morton position in the tile), item % spp the sample.  A wave draws a chunk of 64 consecutive items
+    // (64-aligned: the samples of the same few pixels of ONE tile) from a ticket counter, works on them in lock-step
+    // and draws the next chunk when all 64 are done.  (Per-pixel items left the frame waiting on single lanes that held
+    // an expensive pixel, 16 samples in sequence; per-lane refill loses the lock-step: 16.2 ms against 11.3 when tried.)
+    constexpr unsigned kChunk = 64;
+    unsigned long long chunk_item0 = 0;  // first item of the chunk this wave holds
     bool exhausted = false;
     // XCD-aware work distribution: the item space is cut into 8 contiguous ranges (bands of tiles), each with
     // its own ticket counter on its own 64-byte line.  A wave starts on the range of the XCD it runs on
@@ -770,45 +762,62 @@ static __device__ __forceinline__ void trace_body() {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
     int range = (int)(xcc & (kRanges - 1)), ranges_done = 0;
-    // In-wave resolve (prm.wave_resolve: spp divides 64 and the wave refills as a whole): the samples of a pixel
-    // then sit in consecutive lanes of one chunk, finished samples wait in the lane's LDS context slot, and when the
-    // whole chunk is done the lane holding sample 0 adds them up in sample order (the reference's foldl) and writes
-    // the pixel -- no sample buffer, no resolve pass.
+    // In-wave resolve (prm.wave_resolve: spp divides 64): the samples of a pixel sit in consecutive lanes of the chunk,
+    // finished samples wait in the lane's LDS context slot, and when the whole chunk is done the lane holding sample 0
+    // adds them up in sample order (the reference's foldl) and writes the pixel -- no sample buffer, no resolve pass.
     bool chunk_pending = false, item_valid = false;
     unsigned long long chunk_t0 = 0;  // when the current chunk was obtained, and the tile it belongs to (a chunk never straddles tiles)
     int chunk_tile = 0;
     unsigned long long ticket_ahead = 0;  // lane 0: ticket of `range` requested ahead of need
     if (lane == 0) ticket_ahead = atomicAdd(kargs()->ticket + range * 8, (unsigned long long)kChunk);
 
+    // this lane's pixel (column, local row) and sample within the chunk the wave holds
+    auto locate = [&](int &px, int &lrow, int &sample) {
+        const auto &prm = kargs()->prm;
+        const unsigned long long item = chunk_item0 + (unsigned)lane;
+        // (this ran 518 k times per frame in every lane: shifts and a corrected float reciprocal where the operands allow it)
+        const unsigned slot = prm.spp_shift >= 0 ? (unsigned)(item >> prm.spp_shift) : (unsigned)(item / (unsigned)prm.spp);
+        sample = (int)(item - (unsigned long long)slot * (unsigned)prm.spp);
+        const int tile = chunk_tile, within = (int)(slot & 63u);
+        int ty = (int)((float)tile * prm.inv_tiles_x), tx = tile - ty * prm.tiles_x;  // tile < 2^24: off by one at most
+        if (tx < 0) { ty--; tx += prm.tiles_x; } else if (tx >= prm.tiles_x) { ty++; tx -= prm.tiles_x; }
+        // Morton order inside the tile: consecutive slots form 2x2, 4x4, ... blocks, so the few pixels a
+        // wave holds at once are neighbours in both directions
+        px = tx * 8 + ((within & 1) | ((within >> 1) & 2) | ((within >> 2) & 4));
+        lrow = ty * 8 + (((within >> 1) & 1) | ((within >> 2) & 2) | ((within >> 3) & 4));
+    };
+
     TIME_DECL;
 #ifdef RAYHS_PROFILE_TIME
     const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime(), mt0_ = __builtin_amdgcn_s_memtime();
 #endif
     while (true) {
-        unsigned long long idle = __ballot(state == ST_DONE);
-        if (chunk_pending && idle == ~0ull) {  // the chunk this wave held is finished
+        if (__ballot(state != ST_DONE) == 0ull) {  // every lane is done: finish the chunk the wave held, draw the next one
             const auto &prm = kargs()->prm;
-            if (prm.wave_resolve && item_valid && sample == 0) {
-                V3 sum = mk(0, 0, 0);
-                auto at = [&](int k) { return mk(cx[CX_A * TRACE_BLOCK + k], cx[(CX_A + 1) * TRACE_BLOCK + k], cx[(CX_A + 2) * TRACE_BLOCK + k]); };
-                int k = 0;
-                for (; k + 4 <= prm.spp; k += 4) {  // foldl (+) black, samples in order (src/RayHs.hs:169-171);
-                    const V3 a = at(k), b = at(k + 1), c = at(k + 2), d = at(k + 3);  // four at a time: one LDS wait, same order of additions
-                    sum = add(add(add(add(sum, a), b), c), d);
+            if (chunk_pending) {
+                if (prm.wave_resolve && item_valid) {
+                    int px, lrow, sample;
+                    locate(px, lrow, sample);
+                    if (sample == 0) {
+                        V3 sum = mk(0, 0, 0);
+                        auto at = [&](int k) { return mk(cx[CX_A * TRACE_BLOCK + k], cx[(CX_A + 1) * TRACE_BLOCK + k], cx[(CX_A + 2) * TRACE_BLOCK + k]); };
+                        int k = 0;
+                        for (; k + 4 <= prm.spp; k += 4) {  // foldl (+) black, samples in order (src/RayHs.hs:169-171);
+                            const V3 a = at(k), b = at(k + 1), c = at(k + 2), d = at(k + 3);  // four at a time: one LDS wait, same order of additions
+                            sum = add(add(add(add(sum, a), b), c), d);
+                        }
+                        for (; k < prm.spp; k++) sum = add(sum, at(k));
+                        store_pixel(kargs()->out, prm.out_format, (size_t)lrow * (size_t)prm.width + (size_t)px, scl(1.0 / (double)prm.spp, sum));
+                    }
                 }
-                for (; k < prm.spp; k++) sum = add(sum, at(k));
-                store_pixel(kargs()->out, prm.out_format, (size_t)lrow * (size_t)prm.width + (size_t)px, scl(1.0 / (double)prm.spp, sum));
+                // how long the chunk took, for the next frame's work order (costs are >= 0: their bit patterns order like the values)
+                if (prm.tile_cost != nullptr && lane == 0)
+                    atomicMax((unsigned *)(prm.tile_cost + chunk_tile), __float_as_uint((float)(__builtin_amdgcn_s_memrealtime() - chunk_t0)));
+                chunk_pending = false;
+                item_valid = false;
             }
-            // how long the chunk took, for the next frame's work order (costs are >= 0: their bit patterns order like the values)
-            if (prm.tile_cost != nullptr && lane == 0)
-                atomicMax((unsigned *)(prm.tile_cost + chunk_tile), __float_as_uint((float)(__builtin_amdgcn_s_memrealtime() - chunk_t0)));
-            chunk_pending = false;
-            item_valid = false;
-        }
-        if (__popcll(idle) < RAYHS_REFILL_MIN) idle = 0ull;
-        while (idle != 0ull && !exhausted) {  // wave-uniform
-            const auto &prm = kargs()->prm;
-            if (pool_next == pool_end) {
+            if (exhausted) break;
+            {
                 unsigned long long *const ticket = kargs()->ticket;
                 const unsigned long long total_items = (unsigned long long)prm.n_tiles * 64ull * (unsigned long long)prm.spp;
                 const unsigned long long per_range = ((total_items + (unsigned long long)kRanges * kChunk - 1) / ((unsigned long long)kRanges * kChunk)) * kChunk;
@@ -820,11 +829,7 @@ static __device__ __forceinline__ void trace_body() {
                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)c);
                     const unsigned long long start = (unsigned long long)range * per_range;
                     const unsigned long long size = start >= total_items ? 0ull : (total_items - start < per_range ? total_items - start : per_range);
-                    if (c < size) {
-                        pool_next = start + c;
-                        pool_end = c + kChunk < size ? start + c + kChunk : start + size;
-                        break;
-                    }
+                    if (c < size) { chunk_item0 = start + c; break; }  // sizes are multiples of 64: the chunk is whole
                     if (++ranges_done == kRanges) { exhausted = true; break; }
                     range = (range + 1) & (kRanges - 1);
                     if (lane == 0) c = atomicAdd(ticket + range * 8, (unsigned long long)kChunk);
@@ -833,7 +838,7 @@ static __device__ __forceinline__ void trace_body() {
                 if (lane == 0) ticket_ahead = atomicAdd(ticket + range * 8, (unsigned long long)kChunk);
                 // a chunk (64 consecutive items, 64-aligned) never straddles tiles: its tile is wave-uniform and comes
                 // through the scalar cache, in the order the previous frame measured, slowest first (rayhs_order_tiles)
-                const unsigned tslot = prm.spp_shift >= 0 ? (unsigned)(pool_next >> (prm.spp_shift + 6)) : (unsigned)(pool_next / ((unsigned long long)prm.spp * 64ull));
+                const unsigned tslot = prm.spp_shift >= 0 ? (unsigned)(chunk_item0 >> (prm.spp_shift + 6)) : (unsigned)(chunk_item0 / ((unsigned long long)prm.spp * 64ull));
                 const int entry = prm.tile_order ? as_const(prm.tile_order)[tslot] : (int)tslot;
                 chunk_tile = entry & kTileMask;
                 if (prm.tile_cost != nullptr) {
@@ -852,44 +857,13 @@ static __device__ __forceinline__ void trace_body() {
                 cnt.c[7]++;  // chunks this wave obtained (lane-0 value is reduced)
                 if (cnt.c[6] == 0) cnt.c[6] = 1;  // waves that obtained any work
 #endif
-            }
-            const unsigned avail = (unsigned)(pool_end - pool_next);
-            const unsigned rank = (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
-            const bool take = ((idle >> lane) & 1ull) && rank < avail;
-            if (take) {
-                const unsigned long long item = pool_next + rank;
-                // (the divisions of this block ran 518 k times per frame in every lane: shifts and a corrected float
-                // reciprocal where the operands allow it)
-                const unsigned slot = prm.spp_shift >= 0 ? (unsigned)(item >> prm.spp_shift) : (unsigned)(item / (unsigned)prm.spp);
-                sample = (int)(item - (unsigned long long)slot * (unsigned)prm.spp);
-                const int tile = chunk_tile;
-                const int within = (int)(slot & 63u);
-                int ty = (int)((float)tile * prm.inv_tiles_x), tx = tile - ty * prm.tiles_x;  // tile < 2^24: off by one at most
-                if (tx < 0) { ty--; tx += prm.tiles_x; } else if (tx >= prm.tiles_x) { ty++; tx -= prm.tiles_x; }
-                // Morton order inside the tile: consecutive slots form 2x2, 4x4, ... blocks, so the few pixels a
-                // wave holds at once are neighbours in both directions
-                px = tx * 8 + ((within & 1) | ((within >> 1) & 2) | ((within >> 2) & 4));
-                lrow = ty * 8 + (((within >> 1) & 1) | ((within >> 2) & 2) | ((within >> 3) & 4));
+                int px, lrow, sample;
+                locate(px, lrow, sample);
                 item_valid = px < prm.width && lrow < prm.n_rows;
-                if (item_valid) {
-                    // local row -> image row (stripe interleave, include/rayhs.h)
-                    if (prm.stripe_count == 1 && prm.stripe_map == nullptr) yrow = prm.row0 + lrow;
-                    else {
-                        const int s_local = prm.stripe_shift >= 0 ? lrow >> prm.stripe_shift : lrow / prm.stripe_rows;
-                        const int in_stripe = lrow - s_local * prm.stripe_rows;
-                        // round-robin ownership, or an explicit list of this device's stripes (rayhs_multi: cost-balanced)
-                        const int s_global = prm.stripe_map ? prm.stripe_map[s_local] : s_local * prm.stripe_count + prm.stripe_rank;
-                        yrow = prm.row0 + s_global * prm.stripe_rows + in_stripe;
-                    }
-                    state = ST_NEW_SAMPLE;
-                }
+                if (item_valid) state = ST_NEW_SAMPLE;
+                chunk_pending = true;
             }
-            const unsigned long long took = __ballot(take);
-            chunk_pending = chunk_pending || took != 0ull;
-            pool_next += (unsigned long long)__popcll(took);
-            idle &= ~took;
         }
-        if (exhausted && __ballot(state != ST_DONE) == 0ull) break;
 
         // ---- advance: consume the last query's answer, run shading up to the next query.
         // Straight-line sections (hit / shadow / exit -> lights -> specular -> return -> next sample)
@@ -949,7 +923,7 @@ static __device__ __forceinline__ void trace_body() {
                         result = ld3(ob.ce); step = A_RETURN;
                     } else if (mat_kind == 4) {  // Transparent: try to transmit (src/RayHs.hs:136-143)
                         V3 refdir;
-                        if (depth != PRM.max_depth && refract(ray.d, c_n, 1.0, ob.ior, refdir)) {
+                        if (fsp != PRM.max_depth && refract(ray.d, c_n, 1.0, ob.ior, refdir)) {
                             c_cd = refdir;  // keep refDir across the exit query
                             ray.o = add(c_p, scl(kEps, refdir)); ray.d = refdir;  // rayEps
                             if (COUNT) cnt.c[CNT_REFRACT_EXIT]++;
@@ -984,7 +958,7 @@ static __device__ __forceinline__ void trace_body() {
                         // suspend this irradiance call: radiance child first, specular child later
                         V3 c_v = LOAD_V();
                         V3 rf = reflect(c_v, c_n);
-                        ws_store(ws, fslot(fsp, FS_KIND), (double)(FR_TRANS_WAIT_RADIANCE + 4 * depth));
+                        ws_store(ws, fslot(fsp, FS_KIND), (double)FR_TRANS_WAIT_RADIANCE);
                         ws_store(ws, fslot(fsp, FS_F), fresnel(ob.fr, dot(c_n, neg(c_v))));
                         ws_store(ws, fslot(fsp, FS_S), dot(rf, c_n));
                         ws_store(ws, fslot(fsp, FS_K), ob.one_m_r0);
@@ -992,7 +966,6 @@ static __device__ __forceinline__ void trace_body() {
                         ws_store3(ws, fslot(fsp, FS_RD), rf);
                         fsp++;
                         ray.o = add(outp, scl(kEps, outdir)); ray.d = outdir;
-                        depth = depth + 1;
                         if (COUNT) cnt.c[CNT_REFRACT]++;
                         qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
                     }
@@ -1049,15 +1022,14 @@ static __device__ __forceinline__ void trace_body() {
                 const auto &ob = rec(SC.objects, c_obj);
                 V3 c_v = LOAD_V();
                 double F = fresnel(ob.fr, dot(c_n, neg(c_v)));
-                if (depth < PRM.max_depth) {
+                if (fsp < PRM.max_depth) {
                     V3 rf = reflect(c_v, c_n);
-                    ws_store(ws, fslot(fsp, FS_KIND), (double)((spec_with_A ? FR_PLASTIC : FR_MIRROR) + 4 * depth));
+                    ws_store(ws, fslot(fsp, FS_KIND), (double)(spec_with_A ? FR_PLASTIC : FR_MIRROR));
                     ws_store(ws, fslot(fsp, FS_F), F);
                     ws_store(ws, fslot(fsp, FS_S), dot(rf, c_n));
                     if (spec_with_A) ws_store3(ws, fslot(fsp, FS_A), c_A);
                     fsp++;
                     ray.o = add(c_p, scl(kEps, rf)); ray.d = rf;
-                    depth = depth + 1;
                     if (COUNT) cnt.c[CNT_REFLECT]++;
                     qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
                 } else {
@@ -1072,15 +1044,20 @@ static __device__ __forceinline__ void trace_body() {
             while (step == A_RETURN) {
                 LOOP_TICK(28);
                 if (fsp == 0) {
-                    const size_t pix = (size_t)lrow * (size_t)PRM.width + (size_t)px;
-                    if (PRM.wave_resolve) {
+                    const auto &prm = kargs()->prm;
+                    if (prm.wave_resolve) {
                         cx_store3(cx, CX_A, result);  // waits in LDS for the in-wave resolve (the A slot is free now)
-                    } else if (PRM.spp > 1) {
-                        // one sample of distributedTracePixel (src/RayHs.hs:173-183); rayhs_resolve folds them in order
-                        double *sb = PRM.sbuf + (pix * (size_t)PRM.spp + (size_t)sample) * 3;
-                        sb[0] = result.x; sb[1] = result.y; sb[2] = result.z;
                     } else {
-                        store_pixel(kargs()->out, PRM.out_format, pix, result);
+                        int px, lrow, sample;
+                        locate(px, lrow, sample);
+                        const size_t pix = (size_t)lrow * (size_t)prm.width + (size_t)px;
+                        if (prm.spp > 1) {
+                            // one sample of distributedTracePixel (src/RayHs.hs:173-183); rayhs_resolve folds them in order
+                            double *sb = prm.sbuf + (pix * (size_t)prm.spp + (size_t)sample) * 3;
+                            sb[0] = result.x; sb[1] = result.y; sb[2] = result.z;
+                        } else {
+                            store_pixel(kargs()->out, prm.out_format, pix, result);
+                        }
                     }
                     if (COUNT) cnt.c[CNT_PIXELS]++;
                     state = ST_DONE;
@@ -1100,10 +1077,10 @@ static __device__ __forceinline__ void trace_body() {
                         fsp = lv;
                     } else if (kind == FR_TRANS_WAIT_RADIANCE) {
                         ws_store3(ws, fslot(lv, FS_A), result);
-                        ws_store(ws, fslot(lv, FS_KIND), (double)(FR_TRANS_WAIT_SPEC + (kd & ~3)));
+                        ws_store(ws, fslot(lv, FS_KIND), (double)FR_TRANS_WAIT_SPEC);
                         ray.o = ws_load3(ws, fslot(lv, FS_RO));
                         ray.d = ws_load3(ws, fslot(lv, FS_RD));
-                        depth = (kd >> 2) + 1;
+                        // (the frame stays suspended: the reflected ray runs at this frame's depth + 1 = fsp)
                         if (COUNT) cnt.c[CNT_REFLECT]++;
                         qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
                     } else {
@@ -1116,8 +1093,19 @@ static __device__ __forceinline__ void trace_body() {
 
             if (state == ST_NEW_SAMPLE) {
                 // pixelCoord (src/Image.hs:31-32) + optional sample offset (src/RayHs.hs:178-188)
-                double fx = (double)px, fy = (double)yrow;
                 const auto &prm = kargs()->prm;
+                int px, lrow, sample, yrow;
+                locate(px, lrow, sample);
+                // local row -> image row (stripe interleave, include/rayhs.h)
+                if (prm.stripe_count == 1 && prm.stripe_map == nullptr) yrow = prm.row0 + lrow;
+                else {
+                    const int s_local = prm.stripe_shift >= 0 ? lrow >> prm.stripe_shift : lrow / prm.stripe_rows;
+                    const int in_stripe = lrow - s_local * prm.stripe_rows;
+                    // round-robin ownership, or an explicit list of this device's stripes (rayhs_multi: cost-balanced)
+                    const int s_global = prm.stripe_map ? prm.stripe_map[s_local] : s_local * prm.stripe_count + prm.stripe_rank;
+                    yrow = prm.row0 + s_global * prm.stripe_rows + in_stripe;
+                }
+                double fx = (double)px, fy = (double)yrow;
                 if (prm.spp > 1) {
                     const uint64_t seed_mixed = mix64(prm.seed + 0x9e3779b97f4a7c15ULL);
                     uint64_t pixel = (uint64_t)px + (uint64_t)prm.width * (uint64_t)yrow;
@@ -1125,7 +1113,7 @@ static __device__ __forceinline__ void trace_body() {
                     fy = fy + (sample01(seed_mixed, pixel, (uint32_t)sample, 1, (uint32_t)prm.spp) - 0.5);
                 }
                 ray = ray_from_pixel(kargs()->cam, fx, fy);
-                depth = 0; fsp = 0;
+                fsp = 0;
                 if (COUNT) cnt.c[CNT_PRIMARY]++;
                 qkind = Q_CLOSEST; state = ST_HIT;
             }
