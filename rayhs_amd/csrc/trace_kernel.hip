@@ -866,15 +866,16 @@ static __device__ __forceinline__ void trace_body() {
         }
 
         // ---- advance: consume the last query's answer, run shading up to the next query.
-        // Straight-line sections (hit / shadow / exit -> lights -> specular -> return -> next sample)
-        // keep the live ranges short; everything declared in this block dies before the query below.
+        // Straight-line sections (hit / shadow / exit -> lights -> specular -> return -> next sample).  The sections talk to
+        // each other through the lane's LDS context slots (P, N, CD, A -- A doubles as the radiance being returned), not
+        // through registers: every V3 that crossed a section boundary in registers had to be copied into place on each
+        // path that reaches the join, and those copies were a quarter of the vector instructions of a round.  The
+        // compiler barriers between the sections keep it from turning the LDS hand-over back into register copies.
         TIME_ADD(0);  // refill
         qkind = Q_NONE;
         occluded = tr.occ;
         if (state != ST_DONE) {
             LOOP_TICK(16);
-            V3 result = mk(0, 0, 0);
-            V3 c_p = mk(0, 0, 0), c_n = mk(0, 0, 0), c_cd = mk(0, 0, 0), c_A = mk(0, 0, 0);
             enum : int { A_NONE, A_LIGHT_NEXT, A_SPEC, A_RETURN, A_QUERY_READY };
             int step = A_NONE;
             bool spec_with_A = false;
@@ -882,12 +883,13 @@ static __device__ __forceinline__ void trace_body() {
             if (state == ST_HIT) {
                 LOOP_TICK(24);
                 // traceRay (src/RayHs.hs:149-154)
-                if (tr.bobj < 0) { result = mk(0, 0, 0); step = A_RETURN; }
+                if (tr.bobj < 0) { cx_store3(cx, CX_A, mk(0, 0, 0)); step = A_RETURN; }
                 else {
                     const auto &ob = rec(SC.objects, tr.bobj);
                     if (COUNT) cnt.c[CNT_SHADED]++;
                     c_obj = tr.bobj;
-                    c_p = add(ray.o, scl(tr.bt, ray.d));  // rayAt (src/Geometry.hs:27-29)
+                    const V3 c_p = add(ray.o, scl(tr.bt, ray.d));  // rayAt (src/Geometry.hs:27-29)
+                    V3 c_n;
                     double hu = 0, hv = 0;
                     const int mat_kind = ob.mat_kind;
                     if (mat_kind == 0 || mat_kind == 2 || mat_kind == 4) PARK_V(ray.d);  // Mirror, Plastic, Transparent: the view direction is read again after the light loop
@@ -910,37 +912,36 @@ static __device__ __forceinline__ void trace_body() {
                         c_n = unit(sub(c_p, ld3(s.c)));
                         if (need_uv) polar_uv(c_n, hu, hv);  // src/Geometry.hs:96
                     }
+                    // the context of the hit being shaded waits in LDS while its rays are traced
+                    cx_store3(cx, CX_P, c_p); cx_store3(cx, CX_N, c_n);
                     // irradiance (src/RayHs.hs:107-147)
                     if (mat_kind == 1 || mat_kind == 2) {  // Diffuse, Plastic
-                        c_cd = ob.cmap_kind == 0 ? ld3(ob.c1) : color_at_slow(as_const(SC.objects), tr.bobj, SC.texels, hu, hv);
-                        c_A = mk(0, 0, 0); c_li = 0;
-                        // the context of the hit being shaded waits in LDS while its shadow rays are traced (A is added per light)
-                        cx_store3(cx, CX_P, c_p); cx_store3(cx, CX_N, c_n); cx_store3(cx, CX_CD, c_cd);
+                        cx_store3(cx, CX_CD, ob.cmap_kind == 0 ? ld3(ob.c1) : color_at_slow(as_const(SC.objects), tr.bobj, SC.texels, hu, hv));
+                        cx_store3(cx, CX_A, mk(0, 0, 0));  // accumDiffuse folds from black
+                        c_li = 0;
                         step = A_LIGHT_NEXT;
                     } else if (mat_kind == 0) {  // Mirror
-                        spec_with_A = false; step = A_SPEC;
+                        step = A_SPEC;
                     } else if (mat_kind == 3) {  // Emmit
-                        result = ld3(ob.ce); step = A_RETURN;
+                        cx_store3(cx, CX_A, ld3(ob.ce)); step = A_RETURN;
                     } else if (mat_kind == 4) {  // Transparent: try to transmit (src/RayHs.hs:136-143)
                         V3 refdir;
                         if (fsp != PRM.max_depth && refract(ray.d, c_n, 1.0, ob.ior, refdir)) {
-                            c_cd = refdir;  // keep refDir across the exit query
+                            cx_store3(cx, CX_CD, refdir);  // keep refDir across the exit query
                             ray.o = add(c_p, scl(kEps, refdir)); ray.d = refdir;  // rayEps
                             if (COUNT) cnt.c[CNT_REFRACT_EXIT]++;
                             qkind = Q_CLOSEST; state = ST_EXIT; step = A_QUERY_READY;
-                        } else { spec_with_A = false; step = A_SPEC; }
-                    } else if (mat_kind == 5) { result = c_n; step = A_RETURN; }   // ShowNormal
-                    else { result = mk(hu, hv, 0); step = A_RETURN; }               // ShowUV
+                        } else step = A_SPEC;
+                    } else if (mat_kind == 5) { cx_store3(cx, CX_A, c_n); step = A_RETURN; }   // ShowNormal
+                    else { cx_store3(cx, CX_A, mk(hu, hv, 0)); step = A_RETURN; }              // ShowUV
                 }
             } else if (state == ST_SHADOW) {
                 // accumDiffuse fold step (src/RayHs.hs:90-96)
-                c_p = cx_load3(cx, CX_P); c_n = cx_load3(cx, CX_N); c_cd = cx_load3(cx, CX_CD);
-                c_A = add(cx_load3(cx, CX_A), occluded ? mk(0, 0, 0) : LOAD_TERM());
+                cx_store3(cx, CX_A, add(cx_load3(cx, CX_A), occluded ? mk(0, 0, 0) : LOAD_TERM()));
                 c_li++;
                 step = A_LIGHT_NEXT;
             } else if (state == ST_EXIT) {
                 // the transmitted ray's exit point (src/RayHs.hs:140-143)
-                c_p = cx_load3(cx, CX_P); c_n = cx_load3(cx, CX_N); c_cd = cx_load3(cx, CX_CD);
                 const auto &ob = rec(SC.objects, c_obj);
                 bool have = false;
                 if (tr.bobj >= 0) {
@@ -953,9 +954,10 @@ static __device__ __forceinline__ void trace_body() {
                     } else if (tr.bprim >= 0) outn = ld3(rec(SC.planes, tr.bprim).n);
                     else outn = unit(sub(outp, ld3(rec(SC.spheres, -tr.bprim - 2).c)));
                     V3 outdir;
-                    if (refract(c_cd, neg(outn), ob.ior, 1.0, outdir)) {
+                    if (refract(cx_load3(cx, CX_CD), neg(outn), ob.ior, 1.0, outdir)) {
                         have = true;
                         // suspend this irradiance call: radiance child first, specular child later
+                        const V3 c_p = cx_load3(cx, CX_P), c_n = cx_load3(cx, CX_N);
                         V3 c_v = LOAD_V();
                         V3 rf = reflect(c_v, c_n);
                         ws_store(ws, fslot(fsp, FS_KIND), (double)FR_TRANS_WAIT_RADIANCE);
@@ -970,56 +972,59 @@ static __device__ __forceinline__ void trace_body() {
                         qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
                     }
                 }
-                if (!have) { spec_with_A = false; step = A_SPEC; }
+                if (!have) step = A_SPEC;
             }
 
+            asm volatile("" ::: "memory");
             TIME_ADD(1);  // hit / shadow / exit sections
-            while (step == A_LIGHT_NEXT) {  // per lane; more than one pass only when a light's term is exactly zero
-                LOOP_TICK(26);
-                if (c_li < SC.n_lights) {
-                    // lightAt (src/Light.hs:12-17) + diffuse (src/Material.hs:31-33)
-                    const auto &L = rec(SC.lights, c_li);
-                    V3 ld, lc;
-                    if (L.kind == 0) { ld = ld3(L.v); lc = ld3(L.c); q_point = false; q_d2 = 0; q_dist = __builtin_inf(); }
-                    else {
-                        V3 dv = sub(ld3(L.v), c_p);
-                        double d = sqrt(dot(dv, dv));
-                        double den = 1.0 + d / L.radius;
-                        double falloff = 1.0 / (den * den);
-                        ld = scl(1 / d, dv);
-                        lc = scl(falloff, ld3(L.c));
-                        q_point = true; q_dist = d;
-                    }
-                    // the light's diffuse term, added after the shadow query if unoccluded
-                    const V3 term = scl(hs_max(dot(ld, c_n), 0) * kPiInv, mulv(c_cd, lc));
-                    // A term of +-0 in every channel (the surface faces away from the light) leaves the running sum as it
-                    // is whether the light is occluded (c + black) or not (c + term): the sum starts at +0 and IEEE addition
-                    // of +-0 to anything but -0 is the identity.  The shadow query cannot matter and is not traced.  (The
-                    // exhaustive kernels trace it: their work counters are the reference's.)
-                    if (!EXH && term.x == 0 && term.y == 0 && term.z == 0) {
-                        if (COUNT) { cnt.c[CNT_SHADOW]++; cnt.c[CNT_SHADOW_SKIPPED]++; }
-                        c_li++;
-                        continue;
-                    }
-                    PARK_TERM(term);
-                    ray.o = add(c_p, scl(kEps, ld)); ray.d = ld;  // rayEps p ld
-                    if (q_point) { V3 dd = sub(ray.o, ld3(L.v)); q_d2 = dot(dd, dd); }  // sqrDist origin p (src/RayHs.hs:87)
-                    if (COUNT) cnt.c[CNT_SHADOW]++;
-                    cx_store3(cx, CX_A, c_A);  // p, n, cd were parked when the hit was found
-                    qkind = Q_SHADOW; state = ST_SHADOW; step = A_QUERY_READY;
-                } else if (rec(SC.objects, c_obj).mat_kind == 1) {
-                    result = add(scl(0.2, c_cd), c_A);  // Diffuse (src/RayHs.hs:111-114)
-                    step = A_RETURN;
-                } else { spec_with_A = true; step = A_SPEC; }  // Plastic (src/RayHs.hs:117-120)
-            }
-            if (state == ST_EXIT && step == A_QUERY_READY) {  // park p, n, refDir across the exit query
-                cx_store3(cx, CX_P, c_p); cx_store3(cx, CX_N, c_n); cx_store3(cx, CX_CD, c_cd);
+            if (step == A_LIGHT_NEXT) {
+                const V3 c_p = cx_load3(cx, CX_P), c_n = cx_load3(cx, CX_N), c_cd = cx_load3(cx, CX_CD);
+                const int n_lights = SC.n_lights;
+                do {  // per lane; more than one pass only when a light's term is exactly zero
+                    LOOP_TICK(26);
+                    if (c_li < n_lights) {
+                        // lightAt (src/Light.hs:12-17) + diffuse (src/Material.hs:31-33)
+                        const auto &L = rec(SC.lights, c_li);
+                        V3 ld, lc;
+                        if (L.kind == 0) { ld = ld3(L.v); lc = ld3(L.c); q_point = false; q_d2 = 0; q_dist = __builtin_inf(); }
+                        else {
+                            V3 dv = sub(ld3(L.v), c_p);
+                            double d = sqrt(dot(dv, dv));
+                            double den = 1.0 + d / L.radius;
+                            double falloff = 1.0 / (den * den);
+                            ld = scl(1 / d, dv);
+                            lc = scl(falloff, ld3(L.c));
+                            q_point = true; q_dist = d;
+                        }
+                        // the light's diffuse term, added after the shadow query if unoccluded
+                        const V3 term = scl(hs_max(dot(ld, c_n), 0) * kPiInv, mulv(c_cd, lc));
+                        // A term of +-0 in every channel (the surface faces away from the light) leaves the running sum as it
+                        // is whether the light is occluded (c + black) or not (c + term): the sum starts at +0 and IEEE addition
+                        // of +-0 to anything but -0 is the identity.  The shadow query cannot matter and is not traced.  (The
+                        // exhaustive kernels trace it: their work counters are the reference's.)
+                        if (!EXH && term.x == 0 && term.y == 0 && term.z == 0) {
+                            if (COUNT) { cnt.c[CNT_SHADOW]++; cnt.c[CNT_SHADOW_SKIPPED]++; }
+                            c_li++;
+                            continue;
+                        }
+                        PARK_TERM(term);
+                        ray.o = add(c_p, scl(kEps, ld)); ray.d = ld;  // rayEps p ld
+                        if (q_point) { V3 dd = sub(ray.o, ld3(L.v)); q_d2 = dot(dd, dd); }  // sqrDist origin p (src/RayHs.hs:87)
+                        if (COUNT) cnt.c[CNT_SHADOW]++;
+                        qkind = Q_SHADOW; state = ST_SHADOW; step = A_QUERY_READY;  // p, n, cd and the running sum A stay parked in LDS
+                    } else if (rec(SC.objects, c_obj).mat_kind == 1) {
+                        cx_store3(cx, CX_A, add(scl(0.2, c_cd), cx_load3(cx, CX_A)));  // Diffuse (src/RayHs.hs:111-114)
+                        step = A_RETURN;
+                    } else { spec_with_A = true; step = A_SPEC; }  // Plastic (src/RayHs.hs:117-120)
+                } while (step == A_LIGHT_NEXT);
             }
 
+            asm volatile("" ::: "memory");
             TIME_ADD(2);  // light section
             if (step == A_SPEC) {
                 // fresnel * specular (src/RayHs.hs:99-104,119,124,132)
                 const auto &ob = rec(SC.objects, c_obj);
+                const V3 c_n = cx_load3(cx, CX_N);
                 V3 c_v = LOAD_V();
                 double F = fresnel(ob.fr, dot(c_n, neg(c_v)));
                 if (fsp < PRM.max_depth) {
@@ -1027,70 +1032,77 @@ static __device__ __forceinline__ void trace_body() {
                     ws_store(ws, fslot(fsp, FS_KIND), (double)(spec_with_A ? FR_PLASTIC : FR_MIRROR));
                     ws_store(ws, fslot(fsp, FS_F), F);
                     ws_store(ws, fslot(fsp, FS_S), dot(rf, c_n));
-                    if (spec_with_A) ws_store3(ws, fslot(fsp, FS_A), c_A);
+                    if (spec_with_A) ws_store3(ws, fslot(fsp, FS_A), cx_load3(cx, CX_A));
                     fsp++;
-                    ray.o = add(c_p, scl(kEps, rf)); ray.d = rf;
+                    ray.o = add(cx_load3(cx, CX_P), scl(kEps, rf)); ray.d = rf;
                     if (COUNT) cnt.c[CNT_REFLECT]++;
                     qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
                 } else {
                     V3 spec = scl(F, mk(0, 0, 0));
-                    result = spec_with_A ? add(c_A, spec) : spec;
+                    if (spec_with_A) spec = add(cx_load3(cx, CX_A), spec);
+                    cx_store3(cx, CX_A, spec);
                     step = A_RETURN;
                 }
             }
 
+            asm volatile("" ::: "memory");
             TIME_ADD(3);  // specular section
-            // hand `result` to the suspended callers until one needs another ray, or the sample is done
-            while (step == A_RETURN) {
-                LOOP_TICK(28);
-                if (fsp == 0) {
-                    const auto &prm = kargs()->prm;
-                    if (prm.wave_resolve) {
-                        cx_store3(cx, CX_A, result);  // waits in LDS for the in-wave resolve (the A slot is free now)
-                    } else {
-                        int px, lrow, sample;
-                        locate(px, lrow, sample);
-                        const size_t pix = (size_t)lrow * (size_t)prm.width + (size_t)px;
-                        if (prm.spp > 1) {
-                            // one sample of distributedTracePixel (src/RayHs.hs:173-183); rayhs_resolve folds them in order
-                            double *sb = prm.sbuf + (pix * (size_t)prm.spp + (size_t)sample) * 3;
-                            sb[0] = result.x; sb[1] = result.y; sb[2] = result.z;
+            // hand the radiance in the A slot to the suspended callers until one needs another ray, or the sample is done
+            if (step == A_RETURN) {
+                V3 result = cx_load3(cx, CX_A);
+                bool changed = false;
+                do {
+                    LOOP_TICK(28);
+                    if (fsp == 0) {
+                        const auto &prm = kargs()->prm;
+                        if (prm.wave_resolve) {
+                            if (changed) cx_store3(cx, CX_A, result);  // waits in the A slot for the in-wave resolve
                         } else {
-                            store_pixel(kargs()->out, prm.out_format, pix, result);
+                            int px, lrow, sample;
+                            locate(px, lrow, sample);
+                            const size_t pix = (size_t)lrow * (size_t)prm.width + (size_t)px;
+                            if (prm.spp > 1) {
+                                // one sample of distributedTracePixel (src/RayHs.hs:173-183); rayhs_resolve folds them in order
+                                double *sb = prm.sbuf + (pix * (size_t)prm.spp + (size_t)sample) * 3;
+                                sb[0] = result.x; sb[1] = result.y; sb[2] = result.z;
+                            } else {
+                                store_pixel(kargs()->out, prm.out_format, pix, result);
+                            }
+                        }
+                        if (COUNT) cnt.c[CNT_PIXELS]++;
+                        state = ST_DONE;
+                        step = A_NONE;
+                    } else {
+                        int lv = fsp - 1;
+                        // one batch of loads per level (a single memory round trip): what every kind but MIRROR reads
+                        const int kind = (int)ws_load(ws, fslot(lv, FS_KIND));
+                        const double F = ws_load(ws, fslot(lv, FS_F)), S = ws_load(ws, fslot(lv, FS_S));
+                        const V3 fA = ws_load3(ws, fslot(lv, FS_A));
+                        changed = true;
+                        if (kind == FR_PLASTIC) {
+                            result = add(fA, scl(F, scl(S, result)));
+                            fsp = lv;
+                        } else if (kind == FR_MIRROR) {
+                            result = scl(F, scl(S, result));
+                            fsp = lv;
+                        } else if (kind == FR_TRANS_WAIT_RADIANCE) {
+                            ws_store3(ws, fslot(lv, FS_A), result);
+                            ws_store(ws, fslot(lv, FS_KIND), (double)FR_TRANS_WAIT_SPEC);
+                            ray.o = ws_load3(ws, fslot(lv, FS_RO));
+                            ray.d = ws_load3(ws, fslot(lv, FS_RD));
+                            // (the frame stays suspended: the reflected ray runs at this frame's depth + 1 = fsp)
+                            if (COUNT) cnt.c[CNT_REFLECT]++;
+                            qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
+                        } else {
+                            double K = ws_load(ws, fslot(lv, FS_K));
+                            result = add(scl(K, fA), scl(F, scl(S, result)));
+                            fsp = lv;
                         }
                     }
-                    if (COUNT) cnt.c[CNT_PIXELS]++;
-                    state = ST_DONE;
-                    step = A_NONE;
-                } else {
-                    int lv = fsp - 1;
-                    // one batch of loads per level (a single memory round trip): what every kind but MIRROR reads
-                    const int kd = (int)ws_load(ws, fslot(lv, FS_KIND));
-                    const double F = ws_load(ws, fslot(lv, FS_F)), S = ws_load(ws, fslot(lv, FS_S));
-                    const V3 fA = ws_load3(ws, fslot(lv, FS_A));
-                    const int kind = kd & 3;
-                    if (kind == FR_PLASTIC) {
-                        result = add(fA, scl(F, scl(S, result)));
-                        fsp = lv;
-                    } else if (kind == FR_MIRROR) {
-                        result = scl(F, scl(S, result));
-                        fsp = lv;
-                    } else if (kind == FR_TRANS_WAIT_RADIANCE) {
-                        ws_store3(ws, fslot(lv, FS_A), result);
-                        ws_store(ws, fslot(lv, FS_KIND), (double)FR_TRANS_WAIT_SPEC);
-                        ray.o = ws_load3(ws, fslot(lv, FS_RO));
-                        ray.d = ws_load3(ws, fslot(lv, FS_RD));
-                        // (the frame stays suspended: the reflected ray runs at this frame's depth + 1 = fsp)
-                        if (COUNT) cnt.c[CNT_REFLECT]++;
-                        qkind = Q_CLOSEST; state = ST_HIT; step = A_QUERY_READY;
-                    } else {
-                        double K = ws_load(ws, fslot(lv, FS_K));
-                        result = add(scl(K, fA), scl(F, scl(S, result)));
-                        fsp = lv;
-                    }
-                }
+                } while (step == A_RETURN);
             }
 
+            asm volatile("" ::: "memory");
             if (state == ST_NEW_SAMPLE) {
                 // pixelCoord (src/Image.hs:31-32) + optional sample offset (src/RayHs.hs:178-188)
                 const auto &prm = kargs()->prm;
