@@ -719,6 +719,8 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
             if (std::getenv("RAYHS_DEBUG_COUNTERS"))
                 std::fprintf(stderr, "rayhs traversal[32..39]: in-traversal %llu %llu | holding-leaf %llu %llu | lane-visits in passes <16 / <32 lanes: %llu %llu | entering %llu %llu\n",
                              c[32], c[33], c[34], c[35], c[36], c[37], c[38], c[39]);
+            if (std::getenv("RAYHS_DEBUG_COUNTERS"))
+                std::fprintf(stderr, "rayhs packet[40..43]: packet visits (lanes, waves) %llu %llu | %llu %llu\n", c[40], c[41], c[42], c[43]);
         }
     }
     return RAYHS_OK;

@@ -361,7 +361,7 @@ struct Tracer {
     }
 
     // triangleIntersection (src/Mesh.hs:59-72)
-    __device__ __forceinline__ bool tri_test(const DTri &tr, const Ray &r, double &t, double &u, double &v) {
+    template <class TR> __device__ __forceinline__ bool tri_test(const TR &tr, const Ray &r, double &t, double &u, double &v) {
         V3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
         V3 p = cross(r.d, e2);
         double det = dot(e1, p);
@@ -621,8 +621,83 @@ struct Tracer {
             float limf = f32_up(lim - te);
             const int obj = me.obj;
             stop_traversal();
-            if (enter) t_cur = me.froot;
             if (enter) { LOOP_TICK(38); }
+#ifndef RAYHS_NO_PACKET
+            // Coherent wave -> packet traversal.  The lanes of a wave hold samples of the same few pixels, and their rays of
+            // one round are of one kind (primary, or shadow rays towards the same light from neighbouring points): when
+            // all entering rays point into the same octant the wave walks the BVH as ONE packet -- one current node and one
+            // stack for the wave (scalar), every node and every leaf triangle fetched once through the scalar cache, both
+            // child boxes tested by all lanes, a subtree entered if ANY lane's ray meets its box, the child that more lanes
+            // prefer first.  No per-lane stack traffic, no per-lane child bookkeeping (30 instead of 55 vector
+            // instructions per visit), and no tail of a few long rays walking alone while the other lanes idle: the packet
+            // ends when its last lane is done, after about as many visits as its longest ray needed.  Boxes only cull, the
+            // triangle tests and the tie rule are the per-lane path's, so the answer is the same.  Waves whose rays
+            // disagree on the octant (reflections off the model) keep the per-lane walk below.
+            const unsigned long long em = __ballot(enter);
+            const unsigned long long nx = __ballot(enter && ix < 0.0f), ny = __ballot(enter && iy < 0.0f), nz = __ballot(enter && iz < 0.0f);
+#ifdef RAYHS_PACKET_ALWAYS
+            if (true) {
+#else
+            if ((nx == 0ull || nx == em) && (ny == 0ull || ny == em) && (nz == 0ull || nz == em)) {
+#endif
+                const stack_ptr wstack = stack - (int)(__lane_id());  // lane 0's column serves as the wave's stack
+                bool live = enter;
+                int cur = me.froot, sp = 0;
+                while (true) {
+                    LOOP_TICK(40);
+                    const auto &nd = as_const(fnodes)[cur];
+                    const int c0 = nd.c0, c1 = nd.c1;
+                    float tn0, tn1;
+                    const bool h0 = pbox(nd.b0, t_ax, t_ay, t_az, t_bx, t_by, t_bz, limf, tn0) && live && c0 != FNODE_NONE;
+                    const bool h1 = pbox(nd.b1, t_ax, t_ay, t_az, t_bx, t_by, t_bz, limf, tn1) && live && c1 != FNODE_NONE;
+                    if (COUNT && live) cnt.c[CNT_NODES] += (c0 != FNODE_NONE) + (c1 != FNODE_NONE);
+                    const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+                    // the child that more of the lanes that hit something would take first
+                    const unsigned long long pref0 = __ballot(h0 && (!h1 || tn0 <= tn1));
+                    const bool first0 = __popcll(pref0) >= __popcll((m0 | m1) & ~pref0);
+                    int next = FNODE_NONE;
+                    for (int side = 0; side < 2; side++) {
+                        const bool zero = (side == 0) == first0;
+                        const int c = zero ? c0 : c1;
+                        if ((zero ? m0 : m1) == 0ull) continue;
+                        if (c >= 0) {  // inner child: walk it next, or after the first one
+                            if (next == FNODE_NONE) next = c;
+                            else { wstack[sp * TRACE_BLOCK] = (StackT)c; sp++; }
+                            continue;
+                        }
+                        // leaf: its (<= 3) triangles, each fetched once for the wave; the reference's fp64 test on the ORIGINAL ray
+                        const bool mine = (zero ? h0 : h1) && live;
+                        const int ref = ~c, first = ref >> 3, n = ref & 7;
+                        for (int k = first; k < first + n; k++) {
+                            const auto &tr = as_const(ftris)[k];
+                            if (COUNT && mine) cnt.c[CNT_TRIS]++;
+                            if (mine) { LOOP_TICK(30); }
+                            double t, u, v;
+                            if (mine && tri_test(tr, r, t, u, v)) {
+                                bool admitted = true;
+                                if (u < kEdgeBand || v < kEdgeBand || (u + v) > 1 - kEdgeBand)
+                                    admitted = reference_path_admits(SC.nodes, rec(SC.fattrs, k).leaf_node, r.o, r.d);
+                                if (admitted) {
+                                    if (shadow) occ = occ || in_front(r, t, point_light, light_d2);
+                                    else if (offer(t, u, v, obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - (double)t_enter); }
+                                }
+                            }
+                        }
+                        if (shadow && occ) live = false;  // any occluder settles a shadow query
+                    }
+                    if (next == FNODE_NONE) {
+                        if (sp == 0) break;
+                        sp--;
+                        next = __builtin_amdgcn_readfirstlane((int)wstack[sp * TRACE_BLOCK]);
+                    }
+                    cur = next;
+                    if (__ballot(live) == 0ull) break;
+                }
+                TIME_ADD(13);
+                continue;
+            }
+#endif
+            if (enter) t_cur = me.froot;
             TIME_ADD(12);
             while (true) {
                 // phase 1: walk inner nodes until this lane holds a leaf (or runs out of nodes).  The body is
