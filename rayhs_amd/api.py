@@ -78,7 +78,10 @@ class RenderDesc:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: the module globals may already be gone
+            pass
 
 
 class Rendering:
@@ -141,7 +144,10 @@ class Rendering:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: the module globals may already be gone
+            pass
 
 
 class MultiRendering:
@@ -191,7 +197,10 @@ class MultiRendering:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: the module globals may already be gone
+            pass
 
 
 def build_rendering(path, device=0, **overrides):
