@@ -446,7 +446,6 @@ struct Tracer {
             const auto &pl = planes[i];
             // outside the exhaustive kernels a shadow query skips Emmit objects and stops at its first occluder
             const bool consider = active && (EXH || !(shadow && (occluded || !pl.occluder)));
-            if (__ballot(consider) == 0ull) continue;
             if (COUNT && consider) cnt.c[CNT_PRIMS]++;
             if (consider) { LOOP_TICK(18); }
             double num, den;
@@ -459,16 +458,17 @@ struct Tracer {
             const double s_far = (q * q) * a;
             const bool beyond_light = shadow && point_light && s_far * (1.0 - 1e-4) > light_d2 && s_far > o_guard;
             const bool wanted = consider && quotient_may_be_positive(num, den) && !beyond_light;
-            if (__ballot(wanted) == 0ull) continue;
-            if (wanted) { LOOP_TICK(20); }
-            const double t = num / den;
-            const bool hit = consider && fabs(den) > 0 && t > 0;
-            if (wave_shadow != 0ull && __ballot(hit && shadow) != 0ull) {
+            // one wave-level branch per plane: everything above is straight-line and predicated (the loop ran six
+            // conditional branches per plane before, and they cost more than the arithmetic they skipped)
+            if (__ballot(wanted) != 0ull) {
+                if (wanted) { LOOP_TICK(20); }
+                const double t = num / den;
+                const bool hit = consider && fabs(den) > 0 && t > 0;
                 const bool front = in_front(r, t, point_light, light_d2);
                 occluded = occluded || (hit && shadow && pl.occluder != 0 && front);
+                const bool better = hit && !shadow && (t < bt || (t == bt && pl.obj < bobj));
+                bt = better ? t : bt; bobj = better ? pl.obj : bobj; bprim = better ? i : bprim;
             }
-            const bool better = hit && !shadow && (t < bt || (t == bt && pl.obj < bobj));
-            bt = better ? t : bt; bobj = better ? pl.obj : bobj; bprim = better ? i : bprim;
         }
         const auto spheres = as_const(SC.spheres);
         for (int i = 0; i < n_spheres && wave_active != 0ull; i++) {
