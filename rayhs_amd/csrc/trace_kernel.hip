@@ -295,8 +295,11 @@ struct Tracer {
     Counters &cnt;
 
     // closest-hit record
-    double bt, bu, bv;
-    int bobj, btri, bleaf, brank;
+    // (the barycentrics of a winning triangle are not kept: the shading section re-runs the test on that one triangle,
+    // which yields the same doubles; the tie ranks live only while their mesh is walked)
+    double bt;
+    int bobj, btri;
+    int bleaf, brank;  // reference leaf / rank of the best triangle of the mesh being walked (-1: none yet)
     int bprim;  // winning plane index i, or sphere index as -(i + 2); -1 for a triangle / miss
     bool bref;  // btri indexes the reference-order arrays (hit found by the reference tree), else the BVH-order ones
     bool occ;   // shadow query: an occluder was found
@@ -313,7 +316,7 @@ struct Tracer {
     __device__ __forceinline__ void stop_traversal() { t_cur = FNODE_NONE; t_pa = FNODE_NONE; t_pb = FNODE_NONE; t_sp = 0; }
 
     __device__ Tracer(stack_ptr st, Counters &c) : stack(st), cnt(c) {
-        bt = 0; bu = 0; bv = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; occ = false; armed = false;
+        bt = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; occ = false; armed = false;
         t_ax = t_ay = t_az = t_bx = t_by = t_bz = t_enter = 0;
         stop_traversal();
     }
@@ -391,7 +394,7 @@ struct Tracer {
             else if (leaf_first != bleaf) take = leaf_first > bleaf;
             else take = rank < brank;
         }
-        if (take) { bt = t; bu = u; bv = v; bobj = obj; btri = tri; bleaf = leaf_first; brank = rank; bprim = -1; }
+        if (take) { bt = t; bobj = obj; btri = tri; bleaf = leaf_first; brank = rank; bprim = -1; }
         return take;
     }
 
@@ -429,7 +432,7 @@ struct Tracer {
         const bool active = kind != Q_NONE;
         const bool shadow = kind == Q_SHADOW;
         bool occluded = false;
-        if (active) { bt = __builtin_inf(); bu = 0; bv = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; }
+        if (active) { bt = __builtin_inf(); bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; }
         armed = false;
 
         // ---- planes and spheres: wave-uniform loops, scene constants via scalar loads.  The per-lane
@@ -971,7 +974,9 @@ static __device__ __forceinline__ void trace_body() {
                     const bool need_uv = ((mat_kind == 1 || mat_kind == 2) && ob.cmap_kind != 0) || mat_kind == 6;
                     if (tr.btri >= 0) {
                         const DTriAttr &at = rec(tr.bref ? SC.attrs : SC.fattrs, tr.btri);
-                        double u = tr.bu, v = tr.bv, w = 1 - u - v;
+                        double u, v, t_again;  // the same test on the same ray and triangle: the same doubles as during the walk
+                        tr.tri_test(rec(tr.bref ? SC.tris : SC.ftris, tr.btri), ray, t_again, u, v);
+                        const double w = 1 - u - v;
                         // barycentricInterp u n1 v n2 (1-u-v) n0 (src/Mesh.hs:53-57,73-74)
                         c_n = add(add(scl(u, ld3(at.n1)), scl(v, ld3(at.n2))), scl(w, ld3(at.n0)));
                         if (need_uv) {
@@ -1024,7 +1029,9 @@ static __device__ __forceinline__ void trace_body() {
                     V3 outn;
                     if (tr.btri >= 0) {
                         const DTriAttr &at = rec(tr.bref ? SC.attrs : SC.fattrs, tr.btri);
-                        double u = tr.bu, v = tr.bv, w = 1 - u - v;
+                        double u, v, t_again;
+                        tr.tri_test(rec(tr.bref ? SC.tris : SC.ftris, tr.btri), ray, t_again, u, v);
+                        const double w = 1 - u - v;
                         outn = add(add(scl(u, ld3(at.n1)), scl(v, ld3(at.n2))), scl(w, ld3(at.n0)));
                     } else if (tr.bprim >= 0) outn = ld3(rec(SC.planes, tr.bprim).n);
                     else outn = unit(sub(outp, ld3(rec(SC.spheres, -tr.bprim - 2).c)));
