@@ -361,6 +361,29 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
         for (int g = 0; g < d.n_meshes; g++) if (mesh_used[(size_t)g]) m2.push_back(meshes[(size_t)g]);
         planes.swap(p2); spheres.swap(s2); meshes.swap(m2);
     }
+    // Planes grouped by the single non-zero component of their normal (x, y, z), general position last: for a finite ray
+    // the two dot products of the plane test then consist of ONE product plus two exact zeros (trace_kernel.hip,
+    // plane loop).  Closest-hit ties are decided by the object index, never by the storage order.
+    int plane_axis_end[3] = {0, 0, 0};
+    {
+        auto axis_of = [](const DPlane &p) {
+            for (int c = 0; c < 3; c++)
+                if (p.n[c] != 0 && std::isfinite(p.n[c]) && p.n[(c + 1) % 3] == 0 && p.n[(c + 2) % 3] == 0 && std::isfinite(p.p[0]) && std::isfinite(p.p[1]) &&
+                    std::isfinite(p.p[2]))
+                    return c;
+            return 3;
+        };
+        std::vector<DPlane> grouped;
+        for (int a = 0; a < 4; a++) {
+            for (DPlane p : planes)
+                if (axis_of(p) == a) {
+                    p.nk = a < 3 ? p.n[a] : 0.0; p.pk = a < 3 ? p.p[a] : 0.0;
+                    grouped.push_back(p);
+                }
+            if (a < 3) plane_axis_end[a] = (int)grouped.size();
+        }
+        planes.swap(grouped);
+    }
     std::vector<DLight> lights((size_t)d.n_lights);
     for (int i = 0; i < d.n_lights; i++) {
         DLight &l = lights[(size_t)i];
@@ -390,6 +413,7 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
     if ((rc = upload(s, lights, &s->d.lights))) return fail(rc);
     if ((rc = upload(s, texels, &s->d.texels))) return fail(rc);
     s->d.n_planes = (int)planes.size();
+    for (int a = 0; a < 3; a++) s->d.plane_axis_end[a] = plane_axis_end[a];
     s->d.n_spheres = (int)spheres.size();
     s->d.n_meshes = (int)meshes.size();
     s->d.n_objects = d.n_objects;

@@ -55,6 +55,7 @@ struct DPlane {   // src/Geometry.hs:62, 70-79
     double p[3], n[3];
     int32_t obj, occluder;          // scene object index; 0 for Emmit (never an occluder, src/RayHs.hs:81).  Next to p and n:
                                     // the query loop then gets everything it needs from one scalar-load round trip
+    double nk, pk;                  // planes whose normal has ONE non-zero component k (DScene.plane_axis_end): n[k], p[k]
     double t[3], b[3];              // b = cross t n (only the UV of a shaded hit reads these)
 };
 struct DSphere {  // src/Geometry.hs:63, 81-96
@@ -98,6 +99,9 @@ struct DScene {
     const DLight *lights;
     const double *texels;
     int32_t n_planes, n_spheres, n_meshes, n_objects, n_lights, n_nodes, n_tris, n_fnodes;
+    // planes are stored grouped: [0, plane_axis_end[0]) have a normal along x, [.., [1]) along y, [.., [2]) along z, the
+    // rest are in general position (the query loop runs a body specialised per group; ties go by object index)
+    int32_t plane_axis_end[3], pad_axis;
 };
 
 // Camera constants of rayFromPixel / unproject / lookAt (src/Projection.hs:22-46,

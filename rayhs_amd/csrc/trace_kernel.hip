@@ -47,6 +47,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "device_scene.h"
 
@@ -325,9 +326,17 @@ struct Tracer {
     // Plane (src/Geometry.hs:68-76): time = (n . (p - o)) / (d . n), a hit iff |d . n| > 0 and time > 0.  The two
     // dot products come first: a quotient of operands with opposite signs (or a zero / NaN operand) can never be
     // > 0, whatever the rounding, so when no lane of the wave can hit the division is skipped for the whole wave.
-    template <class PL> __device__ __forceinline__ void plane_terms(const PL &pl, const Ray &r, double &num, double &den) {
-        den = dot(r.d, ld3(pl.n));
-        num = dot(ld3(pl.n), sub(ld3(pl.p), r.o));
+    // AXIS 0..2: the plane's normal has the single non-zero component AXIS (abi.cpp groups the planes so).  For a finite
+    // ray the sums  d.x*n.x + d.y*n.y + d.z*n.z  and  n.(p - o)  then consist of that one product plus two exact zeros,
+    // so the one product is the same double (up to the sign of a zero result, which no comparison below can see).
+    template <int AXIS, class PL> __device__ __forceinline__ void plane_terms(const PL &pl, const Ray &r, double &num, double &den) {
+        if (AXIS == 0) { den = r.d.x * pl.nk; num = pl.nk * (pl.pk - r.o.x); }
+        else if (AXIS == 1) { den = r.d.y * pl.nk; num = pl.nk * (pl.pk - r.o.y); }
+        else if (AXIS == 2) { den = r.d.z * pl.nk; num = pl.nk * (pl.pk - r.o.z); }
+        else {
+            den = dot(r.d, ld3(pl.n));
+            num = dot(ld3(pl.n), sub(ld3(pl.p), r.o));
+        }
     }
     static __device__ __forceinline__ bool quotient_may_be_positive(double num, double den) {
         return (num > 0 && den > 0) || (num < 0 && den < 0);
@@ -445,14 +454,16 @@ struct Tracer {
         const double o_guard = (o_max * o_max) * 1e-18;
         const int n_planes = SC.n_planes, n_spheres = SC.n_spheres, n_meshes = SC.n_meshes;
         const auto planes = as_const(SC.planes);
-        for (int i = 0; i < n_planes && wave_active != 0ull; i++) {
+        auto plane_range = [&](auto axis_tag, int i, const int end) {
+            constexpr int AXIS = decltype(axis_tag)::value;
+            for (; i < end; i++) {
             const auto &pl = planes[i];
             // outside the exhaustive kernels a shadow query skips Emmit objects and stops at its first occluder
             const bool consider = active && (EXH || !(shadow && (occluded || !pl.occluder)));
             if (COUNT && consider) cnt.c[CNT_PRIMS]++;
             if (consider) { LOOP_TICK(18); }
             double num, den;
-            plane_terms(pl, r, num, den);
+            plane_terms<AXIS>(pl, r, num, den);
             // a shadow query only asks whether the hit lies in front of the light: with an approximate quotient
             // (v_rcp_f64, ~1e-8) a plane whose squared hit distance exceeds the light's by more than 1e-4 of it is
             // settled without the division.  (in_front forms |o - (o + t d)|^2; its cancellation error stays
@@ -472,6 +483,16 @@ struct Tracer {
                 const bool better = hit && !shadow && (t < bt || (t == bt && pl.obj < bobj));
                 bt = better ? t : bt; bobj = better ? pl.obj : bobj; bprim = better ? i : bprim;
             }
+            }
+        };
+        if (wave_active != 0ull) {
+            // a ray with a non-finite component (0 * inf = NaN in the reference's sums) forces the general form on everyone
+            const bool all_finite = __ballot(active && !isfinite(((r.d.x + r.d.y) + r.d.z) + ((r.o.x + r.o.y) + r.o.z))) == 0ull;
+            const int ex = all_finite ? SC.plane_axis_end[0] : 0, ey = all_finite ? SC.plane_axis_end[1] : 0, ez = all_finite ? SC.plane_axis_end[2] : 0;
+            plane_range(std::integral_constant<int, 0>(), 0, ex);
+            plane_range(std::integral_constant<int, 1>(), ex, ey);
+            plane_range(std::integral_constant<int, 2>(), ey, ez);
+            plane_range(std::integral_constant<int, 3>(), ez, n_planes);
         }
         const auto spheres = as_const(SC.spheres);
         for (int i = 0; i < n_spheres && wave_active != 0ull; i++) {
