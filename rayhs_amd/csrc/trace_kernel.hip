@@ -329,13 +329,13 @@ struct Tracer {
     // AXIS 0..2: the plane's normal has the single non-zero component AXIS (abi.cpp groups the planes so).  For a finite
     // ray the sums  d.x*n.x + d.y*n.y + d.z*n.z  and  n.(p - o)  then consist of that one product plus two exact zeros,
     // so the one product is the same double (up to the sign of a zero result, which no comparison below can see).
-    template <int AXIS, class PL> __device__ __forceinline__ void plane_terms(const PL &pl, const Ray &r, double &num, double &den) {
-        if (AXIS == 0) { den = r.d.x * pl.nk; num = pl.nk * (pl.pk - r.o.x); }
-        else if (AXIS == 1) { den = r.d.y * pl.nk; num = pl.nk * (pl.pk - r.o.y); }
-        else if (AXIS == 2) { den = r.d.z * pl.nk; num = pl.nk * (pl.pk - r.o.z); }
+    template <int AXIS> __device__ __forceinline__ void plane_terms(double nk, double pk, V3 pn, V3 pp, const Ray &r, double &num, double &den) {
+        if (AXIS == 0) { den = r.d.x * nk; num = nk * (pk - r.o.x); }
+        else if (AXIS == 1) { den = r.d.y * nk; num = nk * (pk - r.o.y); }
+        else if (AXIS == 2) { den = r.d.z * nk; num = nk * (pk - r.o.z); }
         else {
-            den = dot(r.d, ld3(pl.n));
-            num = dot(ld3(pl.n), sub(ld3(pl.p), r.o));
+            den = dot(r.d, pn);
+            num = dot(pn, sub(pp, r.o));
         }
     }
     static __device__ __forceinline__ bool quotient_may_be_positive(double num, double den) {
@@ -457,13 +457,21 @@ struct Tracer {
         auto plane_range = [&](auto axis_tag, int i, const int end) {
             constexpr int AXIS = decltype(axis_tag)::value;
             for (; i < end; i++) {
-            const auto &pl = planes[i];
+            // everything the test reads of the plane, fetched as ONE batch of scalar loads at the top (left to itself the
+            // compiler re-loaded `occluder` and `obj` inside each branch that mentions them: four dependent scalar-cache
+            // round trips per plane)
+            const auto &rec_ = planes[i];
+            const int pl_obj = rec_.obj, pl_occluder = rec_.occluder;
+            double nk = 0, pk = 0;
+            V3 pn = mk(0, 0, 0), pp = mk(0, 0, 0);
+            if (AXIS < 3) { nk = rec_.nk; pk = rec_.pk; asm volatile("" :: "s"(pl_obj), "s"(pl_occluder), "s"(nk), "s"(pk)); }
+            else { pn = ld3(rec_.n); pp = ld3(rec_.p); asm volatile("" :: "s"(pl_obj), "s"(pl_occluder), "s"(pn.x), "s"(pn.y), "s"(pn.z), "s"(pp.x), "s"(pp.y), "s"(pp.z)); }
             // outside the exhaustive kernels a shadow query skips Emmit objects and stops at its first occluder
-            const bool consider = active && (EXH || !(shadow && (occluded || !pl.occluder)));
+            const bool consider = active && (EXH || !(shadow && (occluded || !pl_occluder)));
             if (COUNT && consider) cnt.c[CNT_PRIMS]++;
             if (consider) { LOOP_TICK(18); }
             double num, den;
-            plane_terms<AXIS>(pl, r, num, den);
+            plane_terms<AXIS>(nk, pk, pn, pp, r, num, den);
             // a shadow query only asks whether the hit lies in front of the light: with an approximate quotient
             // (v_rcp_f64, ~1e-8) a plane whose squared hit distance exceeds the light's by more than 1e-4 of it is
             // settled without the division.  (in_front forms |o - (o + t d)|^2; its cancellation error stays
@@ -479,9 +487,9 @@ struct Tracer {
                 const double t = num / den;
                 const bool hit = consider && fabs(den) > 0 && t > 0;
                 const bool front = in_front(r, t, point_light, light_d2);
-                occluded = occluded || (hit && shadow && pl.occluder != 0 && front);
-                const bool better = hit && !shadow && (t < bt || (t == bt && pl.obj < bobj));
-                bt = better ? t : bt; bobj = better ? pl.obj : bobj; bprim = better ? i : bprim;
+                occluded = occluded || (hit && shadow && pl_occluder != 0 && front);
+                const bool better = hit && !shadow && (t < bt || (t == bt && pl_obj < bobj));
+                bt = better ? t : bt; bobj = better ? pl_obj : bobj; bprim = better ? i : bprim;
             }
             }
         };
