@@ -504,7 +504,10 @@ struct Tracer {
         }
         const auto spheres = as_const(SC.spheres);
         for (int i = 0; i < n_spheres && wave_active != 0ull; i++) {
-            const auto &s = spheres[i];
+            // (one batch of scalar loads per sphere, as for the planes)
+            struct { double c[3], r2; int obj, occluder; } s;
+            { const auto &q = spheres[i]; s.c[0] = q.c[0]; s.c[1] = q.c[1]; s.c[2] = q.c[2]; s.r2 = q.r2; s.obj = q.obj; s.occluder = q.occluder; }
+            asm volatile("" :: "s"(s.c[0]), "s"(s.c[1]), "s"(s.c[2]), "s"(s.r2), "s"(s.obj), "s"(s.occluder));
             const bool consider = active && (EXH || !(shadow && (occluded || !s.occluder)));
             if (__ballot(consider) == 0ull) continue;
             if (COUNT && consider) cnt.c[CNT_PRIMS]++;
@@ -664,13 +667,20 @@ struct Tracer {
             // instructions per visit), and no tail of a few long rays walking alone while the other lanes idle: the packet
             // ends when its last lane is done, after about as many visits as its longest ray needed.  Boxes only cull, the
             // triangle tests and the tie rule are the per-lane path's, so the answer is the same.  Waves whose rays
-            // disagree on the octant (reflections off the model) keep the per-lane walk below.
+            // neither share an octant nor form a narrow cone (reflections off the model) keep the per-lane walk below.
             const unsigned long long em = __ballot(enter);
             const unsigned long long nx = __ballot(enter && ix < 0.0f), ny = __ballot(enter && iy < 0.0f), nz = __ballot(enter && iz < 0.0f);
 #ifdef RAYHS_PACKET_ALWAYS
             if (true) {
 #else
-            if ((nx == 0ull || nx == em) && (ny == 0ull || ny == em) && (nz == 0ull || nz == em)) {
+            // ... or into a narrow cone (within ~25 degrees) around the first entering ray's direction: shadow rays
+            // converging on a near light straddle an axis without being any less of a bundle
+            const int lead_lane = __ffsll((unsigned long long)em) - 1;
+            const float dx = (float)r.d.x, dy = (float)r.d.y, dz = (float)r.d.z;
+            const float lx = __shfl(dx, lead_lane), ly = __shfl(dy, lead_lane), lz = __shfl(dz, lead_lane);
+            const float cosine = (dx * lx + dy * ly + dz * lz) * __builtin_amdgcn_rsqf((dx * dx + dy * dy + dz * dz) * (lx * lx + ly * ly + lz * lz));
+            const bool cone = __ballot(enter && !(cosine > 0.9f)) == 0ull;
+            if (cone || ((nx == 0ull || nx == em) && (ny == 0ull || ny == em) && (nz == 0ull || nz == em))) {
 #endif
                 const stack_ptr wstack = stack - (int)(__lane_id());  // lane 0's column serves as the wave's stack
                 bool live = enter;
