@@ -628,7 +628,15 @@ struct Tracer {
         const FNode *const fnodes = SC.fnodes;
         const DTri *const ftris = SC.ftris;
         for (int m = 0; m < n_meshes; m++) {  // wave-uniform
-            const auto &me = meshes[m];
+            // (what the set-up reads of the mesh record, in one batch of scalar loads)
+            struct { int obj, occluder, froot; double center[3]; float flo[3], fhi[3]; } me;
+            {
+                const auto &q = meshes[m];
+                me.obj = q.obj; me.occluder = q.occluder; me.froot = q.froot;
+                for (int k = 0; k < 3; k++) { me.center[k] = q.center[k]; me.flo[k] = q.flo[k]; me.fhi[k] = q.fhi[k]; }
+            }
+            asm volatile("" :: "s"(me.obj), "s"(me.occluder), "s"(me.froot), "s"(me.center[0]), "s"(me.center[1]), "s"(me.center[2]), "s"(me.flo[0]),
+                         "s"(me.flo[1]), "s"(me.flo[2]), "s"(me.fhi[0]), "s"(me.fhi[1]), "s"(me.fhi[2]));
             if (me.froot == FNODE_NONE) continue;
             // a shadow query skips Emmit objects and stops at its first occluder
             const bool want = armed && !(shadow && (occ || !me.occluder));
@@ -1105,7 +1113,7 @@ static __device__ __forceinline__ void trace_body() {
                     LOOP_TICK(26);
                     if (c_li < n_lights) {
                         // lightAt (src/Light.hs:12-17) + diffuse (src/Material.hs:31-33)
-                        const auto &L = rec(SC.lights, c_li);
+                        const DLight L = rec(SC.lights, c_li);  // by value: the whole 64-byte record in one batch of loads, not field by field per branch
                         V3 ld, lc;
                         if (L.kind == 0) { ld = ld3(L.v); lc = ld3(L.c); q_point = false; q_d2 = 0; q_dist = __builtin_inf(); }
                         else {
