@@ -73,13 +73,17 @@ struct DMesh {
     float flo[3], fhi[3];           // bounds of the mesh in those coordinates, rounded outward and inflated
 };
 struct DObject {  // Material (src/Material.hs:13-19) + ColorMap (src/ColorMap.hs:11-16) of one object
+    // the first 64 bytes are what shading a hit reads (DObjectHot): fetched per lane as one batch of four 16-byte loads
     int32_t mat_kind, cmap_kind, tex_w, tex_h;
-    int64_t tex_off;
+    double c1[3];       // flat colour / checker color1
     double ior;
     double fr;          // r0 1.0 ior  (src/Material.hs:28)
     double one_m_r0;    // 1 - r0 ior 1.0 (src/RayHs.hs:133)
-    double ce[3], c1[3], c2[3], size;
+    double ce[3], c2[3], size;
+    int64_t tex_off;
 };
+struct DObjectHot { int32_t mat_kind, cmap_kind, tex_w, tex_h; double c1[3], ior, fr, one_m_r0; };
+static_assert(sizeof(DObjectHot) == 64, "the hot head of DObject is one 64-byte fetch");
 struct DLight {   // src/Light.hs:8-10
     int32_t kind, pad;
     double v[3], c[3], radius;

@@ -1010,7 +1010,8 @@ static __device__ __forceinline__ void trace_body() {
                 // traceRay (src/RayHs.hs:149-154)
                 if (tr.bobj < 0) { cx_store3(cx, CX_A, mk(0, 0, 0)); step = A_RETURN; }
                 else {
-                    const auto &ob = rec(SC.objects, tr.bobj);
+                    const DObject *const objects = SC.objects;
+                    const DObjectHot ob = *(const DObjectHot *)&rec(objects, tr.bobj);  // by value: one batch of loads, not field by field per branch
                     if (COUNT) cnt.c[CNT_SHADED]++;
                     c_obj = tr.bobj;
                     const V3 c_p = add(ray.o, scl(tr.bt, ray.d));  // rayAt (src/Geometry.hs:27-29)
@@ -1050,7 +1051,7 @@ static __device__ __forceinline__ void trace_body() {
                     } else if (mat_kind == 0) {  // Mirror
                         step = A_SPEC;
                     } else if (mat_kind == 3) {  // Emmit
-                        cx_store3(cx, CX_A, ld3(ob.ce)); step = A_RETURN;
+                        cx_store3(cx, CX_A, ld3(rec(objects, tr.bobj).ce)); step = A_RETURN;
                     } else if (mat_kind == 4) {  // Transparent: try to transmit (src/RayHs.hs:136-143)
                         V3 refdir;
                         if (fsp != PRM.max_depth && refract(ray.d, c_n, 1.0, ob.ior, refdir)) {
