@@ -14,36 +14,46 @@
 //
 // How it runs here (not how the reference runs):
 //   * Persistent waves: a fixed grid sized to the chip.  Work items are (pixel, sample) pairs in
-//     Morton order inside 8x8-pixel tiles; a wave draws 64 consecutive items from the ticket counter of
-//     its XCD's band of the frame (8 bands, requested one chunk ahead, next band when dry) and refills
-//     as a whole, so its lanes hold the samples of the same few pixels and stay in lock-step.  When spp
-//     divides 64 a pixel's samples sit in one chunk and are folded in sample order (the reference's
-//     foldl) inside the wave; any other spp > 1 goes through a sample buffer and rayhs_resolve.
+//     Morton order inside 8x8-pixel tiles; a wave draws a chunk of 64 consecutive items from the ticket
+//     counter of its XCD's band of the frame (8 bands, requested one chunk ahead, next band when dry),
+//     works on it in lock-step -- its lanes hold samples of the same few pixels -- and draws the next
+//     one when all 64 are done.  Tiles are handed out slowest-first: by the chunk times the previous
+//     frame of the same geometry measured, or by a static estimate for the first frame
+//     (rayhs_static_costs, rayhs_order_tiles).  When spp divides 64 a pixel's samples sit in one chunk
+//     and are folded in sample order (the reference's foldl) inside the wave; any other spp > 1 goes
+//     through a sample buffer and rayhs_resolve.
 //   * The recursion of irradiance/specular is an explicit per-lane state machine.  Every lane, whatever
 //     its shading state, funnels into ONE scene query site per iteration, so primary, shadow,
-//     reflection and refraction rays share the traversal loop of a wave.
+//     reflection and refraction rays share the traversal code of a wave.  The sections of the state
+//     machine hand their vectors over through the lane's LDS context slots, not through registers.
+//   * Planes and spheres are wave-uniform loops over records fetched through the scalar cache, one
+//     batch of loads and one wave-level branch per primitive; planes are grouped by the axis of their
+//     normal so that an axis-aligned wall costs one product per dot product.
 //   * Mesh traversal uses the BVH of bvh_build.cpp: 64-byte nodes holding both children's boxes as
-//     mesh-centred fp32 planes (one packed fused multiply-add per axis, culling only), a per-lane stack
-//     of inner-node indices in LDS (level-major: bank-conflict free), nearest child first, pruning
-//     against the closest hit so far, any-hit exit for shadow queries, and a branch-free while-while
-//     loop that postpones leaves so that the fp64 triangle tests run with many lanes active.  Boxes
-//     only decide which triangles are tested; the winner is the reference's because every triangle test
-//     is the reference's fp64 Moller-Trumbore and ties are resolved by its rule (first triangle in a
-//     leaf, right-most leaf, first scene object).  Where the reference's own fp64 boxes are NOT a
-//     conservative cull its behaviour is replayed: rays with a (near-)zero direction component walk the
-//     reference tree (meshes_reference), near-edge hits are checked against the reference's box path
+//     mesh-centred fp32 planes (one packed fused multiply-add per axis, culling only).  A wave whose
+//     entering rays share an octant or form a narrow cone walks it as ONE packet (one node, one stack,
+//     scalar fetches for the whole wave); otherwise every lane walks on its own with a stack of
+//     inner-node indices in LDS (level-major: bank-conflict free), nearest child first, leaves
+//     postponed so that the fp64 triangle tests run with many lanes active.  Both prune against the
+//     closest hit and leave on any hit for shadow queries.  Boxes only decide which triangles are
+//     tested; the winner is the reference's because every triangle test is the reference's fp64
+//     Moller-Trumbore and ties are resolved by its rule (first triangle in a leaf, right-most leaf,
+//     first scene object).  Where the reference's own fp64 boxes are NOT a conservative cull its
+//     behaviour is replayed: rays with a (near-)zero direction component walk the reference tree
+//     (meshes_reference), near-edge hits are checked against the reference's box path
 //     (reference_path_admits).
 //   * The exhaustive kernels walk the reference's own tree for every ray (fp64 boxes, both children
 //     always) and visit exactly its node set.
 //   * Everything that enters a result is fp64 like the reference.  Built twice: "exact"
 //     (-ffp-contract=off, same operations as the reference/oracle, the default) and "fast" (fused
 //     multiply-add allowed, RAYHS_FLAG_FMA).
-//   * To run 4 waves per SIMD the kernel must fit 128 VGPRs: the shading context of a hit (p, n, cd, A
-//     and, when LDS has room, the light term) is parked in LDS across shadow and exit queries; the view
-//     direction and the continuation frames of suspended irradiance calls live in a global workspace
-//     (slot-major so lanes coalesce).
+//   * To run 4 waves per SIMD the kernel must fit 128 VGPRs and 40 KiB of LDS per workgroup: the
+//     shading context of a hit (p, n, cd, A and, when LDS has room, the light term) lives in LDS; the
+//     view direction and the continuation frames of suspended irradiance calls in a global workspace
+//     (slot-major so lanes coalesce); kernel arguments are read from the kernarg segment where they
+//     are used instead of being held in SGPRs (KArgs).
 // Development switches: RAYHS_PROFILE_LOOPS / RAYHS_PROFILE_TIME (diagnostic builds with trip counters
-// or s_memtime stamps, read with RAYHS_DEBUG_COUNTERS=1).
+// or s_memtime stamps, read with RAYHS_DEBUG_COUNTERS=1), RAYHS_NO_PACKET / RAYHS_PACKET_ALWAYS.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
