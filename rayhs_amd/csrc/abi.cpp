@@ -556,7 +556,7 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     return RAYHS_OK;
 }
 
-static int ensure_workspace(const rayhs_scene *s, const DParams &dp) {
+static int ensure_workspace(const rayhs_scene *s, const DParams &dp, hipStream_t st) {
     size_t need = ((size_t)LANE_SLOTS + (size_t)std::max(dp.max_depth, 1) * FRAME_SLOTS) * (size_t)dp.frame_stride * sizeof(double);
     if (need >= ((size_t)1 << 32) || dp.frame_stride >= (1 << 24))  // 32-bit byte offsets / 24-bit multiplies in the kernel
         return set_error(RAYHS_ERR_INVALID, "max_depth %d needs a %zu-byte continuation workspace; the limit is 4 GiB", dp.max_depth, need);
@@ -566,6 +566,9 @@ static int ensure_workspace(const rayhs_scene *s, const DParams &dp) {
         void *p = nullptr;
         HIP_TRY(hipMalloc(&p, need));
         s->frames = (double *)p; s->frames_bytes = need;
+        // touch the fresh pages once, in stream order, in front of the first frame: its kernel otherwise pays the first
+        // touch of ~100 MB inside its own time (4-5 % of a 1080p frame, tools/first_frame.py)
+        HIP_TRY(hipMemsetAsync(p, 0, need, st));
     }
     // spp > 1: one radiance triple per (pixel, sample), folded in sample order by rayhs_resolve
     size_t sneed = dp.spp > 1 && !dp.wave_resolve ? (size_t)dp.n_rows * (size_t)dp.width * (size_t)dp.spp * 3 * sizeof(double) : 0;
@@ -636,7 +639,7 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
     // one first waits for that one to finish (device-side wait, no host synchronisation)
     if (!s->last_done) HIP_TRY(hipEventCreateWithFlags(&s->last_done, hipEventDisableTiming));
     if (s->have_last && s->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, s->last_done, 0));
-    if ((rc = ensure_workspace(s, dp))) return rc;
+    if ((rc = ensure_workspace(s, dp, st))) return rc;
     bool record_costs = false, static_order = false;
     if ((rc = plan_tile_order(s, p, variant, dp, st, record_costs, static_order))) return rc;
     unsigned long long *ticket = s->tickets + (size_t)(s->next_ticket++ % kTicketRings) * kTicketSlots;

@@ -17,7 +17,7 @@ W = {"cornell": ("scenes/cornell_1080p_d0.json", 1), "dragon_low": ("scenes/drag
 def one(name):
     from rayhs_amd import build_rendering, lib as L
     scene, spp = W[name]
-    firsts, steady = [], []
+    firsts, steady, warm = [], [], []
     for rep in range(3):                      # three fresh handles: three first frames
         r = build_rendering(scene)
         img0, st = r.ray_trace(spp=spp, out_format=L.OUT_F32)
@@ -27,9 +27,14 @@ def one(name):
             if i >= 2:
                 steady.append(st["kernel_ms"])
         assert np.array_equal(img, img0)
+        # the same static order once more on the WARM handle (another geometry in between resets the measured order): what is
+        # left of first-over-steady here is the order alone, the rest of it is first touch of fresh buffers (scene, workspace)
+        r.ray_trace(spp=spp, out_format=L.OUT_F32, row1=r.height - 8)
+        warm.append(r.ray_trace(spp=spp, out_format=L.OUT_F32)[1]["kernel_ms"])
         r.close()
     return {"workload": name, "first_frame_ms": sorted(firsts)[1], "steady_ms": sorted(steady)[len(steady) // 2],
             "first_over_steady": sorted(firsts)[1] / sorted(steady)[len(steady) // 2],
+            "first_order_on_warm_handle_ms": sorted(warm)[1], "warm_first_over_steady": sorted(warm)[1] / sorted(steady)[len(steady) // 2],
             "order": "scan" if os.environ.get("RAYHS_NO_STATIC_ORDER") else "static estimate"}
 
 

@@ -19,14 +19,21 @@ os.makedirs(dst, exist_ok=True)
 out = {"workload": wl, "frames_in_flight": 1}
 if os.path.exists(pre + "_kernel_source.sha256"):
     out["kernel_source_sha256"] = open(pre + "_kernel_source.sha256").read().strip()
-for f in glob.glob(f"{pre}_trace/*/*_kernel_stats.csv"):
+def newest(pattern):
+    """gpurun merges a run's files INTO the local gpurun_out/: files of earlier runs stay beside the new ones (they are
+    named by pid).  Only the newest file of a kind belongs to the run being summarised."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
+for f in newest(f"{pre}_trace/*/*_kernel_stats.csv"):
     rows = [r for r in csv.DictReader(open(f))]
     keep = [r for r in rows if r["Name"].startswith("rayhs_") or float(r["Percentage"]) > 0.5]
     with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as g:
         w = csv.DictWriter(g, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
     out["kernel_stats"] = {r["Name"]: {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6, "pct": float(r["Percentage"])} for r in keep}
 # the trace kernel over the TIMED launches only (the --stats average also covers the set-up and warm-up frames)
-for f in glob.glob(f"{pre}_trace/*/*_kernel_trace.csv"):
+for f in newest(f"{pre}_trace/*/*_kernel_trace.csv"):
     try:
         tb = json.load(open(pre + "_trace_bench.json"))
     except Exception:
@@ -38,7 +45,7 @@ for f in glob.glob(f"{pre}_trace/*/*_kernel_trace.csv"):
         out["timed_launches"] = {"kernel": rows[-1]["Kernel_Name"], "launches": steps, "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d),
                                  "bench_events_avg_ms": tb.get("kernel_ms_rank0"), "first_frame_ms": tb.get("first_frame_ms")}
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(f"{pre}_pmc_*/*/*_counter_collection.csv"):
+for f in [g for d in glob.glob(f"{pre}_pmc_*") for g in newest(f"{d}/*/*_counter_collection.csv")]:
     for r in csv.DictReader(open(f)):
         if r["Kernel_Name"].startswith("rayhs_trace") and "count" not in r["Kernel_Name"]:
             pmc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
