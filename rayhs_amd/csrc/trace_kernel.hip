@@ -209,9 +209,12 @@ DEV void store_pixel(void *out, int out_format, size_t pix, V3 c) {
 }
 
 // rare paths kept out of line so that their temporaries do not inflate the kernel's register budget
-static __device__ __attribute__((noinline)) void polar_uv(V3 n, double &u, double &v) {  // polar, src/Geometry.hs:96
-    u = kPiInv * atan(n.z / n.x);
-    v = kPiInv * acos(n.y);
+struct UV2 { double u, v; };
+static __device__ __attribute__((noinline)) UV2 polar_uv(V3 n) {  // polar, src/Geometry.hs:96 (by value: out-references put u and v of EVERY hit into scratch)
+    UV2 r;
+    r.u = kPiInv * atan(n.z / n.x);
+    r.v = kPiInv * acos(n.y);
+    return r;
 }
 static __device__ __attribute__((noinline)) V3 color_at_slow(cptr<DObject> objects, int obj, const double *texels, double u, double v) {
     return color_at(objects[obj], texels, u, v);
@@ -317,19 +320,19 @@ struct Tracer {
 
     bool armed; // begin() left the meshes of this lane's query to the fast BVH (traverse())
 
-    // traversal state of the fast BVH; lives only inside traverse()
-    int t_cur, t_sp;       // current inner node (FNODE_NONE = none), stack depth
-    int t_pa, t_pb;        // postponed leaves
-    float t_ax, t_ay, t_az, t_bx, t_by, t_bz;  // per-plane slab coefficients of the current mesh (see pbox)
-    float t_enter;                             // shift of the traversal origin along the ray
-
-    __device__ __forceinline__ bool traversing() const { return t_cur != FNODE_NONE || t_pa != FNODE_NONE || t_sp > 0; }
-    __device__ __forceinline__ void stop_traversal() { t_cur = FNODE_NONE; t_pa = FNODE_NONE; t_pb = FNODE_NONE; t_sp = 0; }
+    // traversal state of the fast BVH: a local of traverse(), NOT part of the tracer (as members these floats sat in
+    // a scratch slot between the calls, loaded at every entry and stored at every exit)
+    struct Walk {
+        int t_cur, t_sp;       // current inner node (FNODE_NONE = none), stack depth
+        int t_pa, t_pb;        // postponed leaves
+        float t_ax, t_ay, t_az, t_bx, t_by, t_bz;  // per-plane slab coefficients of the current mesh (see pbox)
+        float t_enter;                             // shift of the traversal origin along the ray
+        __device__ __forceinline__ bool traversing() const { return t_cur != FNODE_NONE || t_pa != FNODE_NONE || t_sp > 0; }
+        __device__ __forceinline__ void stop_traversal() { t_cur = FNODE_NONE; t_pa = FNODE_NONE; t_pb = FNODE_NONE; t_sp = 0; }
+    };
 
     __device__ Tracer(stack_ptr st, Counters &c) : stack(st), cnt(c) {
         bt = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; occ = false; armed = false;
-        t_ax = t_ay = t_az = t_bx = t_by = t_bz = t_enter = 0;
-        stop_traversal();
     }
 
     // ---- analytic primitives (src/Geometry.hs:68-96) ----
@@ -597,10 +600,10 @@ struct Tracer {
     // one inner-node visit: both child boxes tested, leaves postponed (nearer first), nearer inner child next, the
     // other pushed.  ND is an FNode in registers (per-lane gather) or behind a constant-address-space reference
     // (wave-uniform visit: the fields are scalar loads and the child references stay in SGPRs).
-    template <class ND> __device__ __forceinline__ void visit(const ND &nd, float limf) {
+    template <class ND> __device__ __forceinline__ void visit(Walk &w, const ND &nd, float limf) {
         float tn0, tn1;
-        const bool h0 = pbox(nd.b0, t_ax, t_ay, t_az, t_bx, t_by, t_bz, limf, tn0) && nd.c0 != FNODE_NONE;
-        const bool h1 = pbox(nd.b1, t_ax, t_ay, t_az, t_bx, t_by, t_bz, limf, tn1) && nd.c1 != FNODE_NONE;
+        const bool h0 = pbox(nd.b0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0) && nd.c0 != FNODE_NONE;
+        const bool h1 = pbox(nd.b1, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn1) && nd.c1 != FNODE_NONE;
         if (COUNT) cnt.c[CNT_NODES] += (nd.c0 != FNODE_NONE) + (nd.c1 != FNODE_NONE);
         const bool near0 = tn0 <= tn1;
         const bool l0 = h0 && nd.c0 < 0, l1 = h1 && nd.c1 < 0;    // hit leaves
@@ -608,20 +611,20 @@ struct Tracer {
         const int cnear = near0 ? nd.c0 : nd.c1, cfar = near0 ? nd.c1 : nd.c0;
         // leaves are postponed, nearer one first
         const bool both_leaves = l0 && l1, any_leaf = l0 || l1;
-        t_pa = both_leaves ? cnear : (l0 ? nd.c0 : (l1 ? nd.c1 : FNODE_NONE));
-        t_pb = both_leaves ? cfar : FNODE_NONE;
+        w.t_pa = both_leaves ? cnear : (l0 ? nd.c0 : (l1 ? nd.c1 : FNODE_NONE));
+        w.t_pb = both_leaves ? cfar : FNODE_NONE;
         // inner children: descend into the nearer, push the other.  The push is an unconditional LDS
         // write to the top-of-stack slot (kept only when sp advances) and the pop an unconditional read,
         // so the loop body has no branches at all.
         const bool both = i0 && i1, any_inner = i0 || i1;
         const int ia = both ? cnear : (i0 ? nd.c0 : nd.c1);
-        stack[t_sp * TRACE_BLOCK] = (StackT)cfar;
-        const int top = t_sp > 0 ? t_sp - 1 : 0;
+        stack[w.t_sp * TRACE_BLOCK] = (StackT)cfar;
+        const int top = w.t_sp > 0 ? w.t_sp - 1 : 0;
         int popped = (int)stack[top * TRACE_BLOCK];
         asm volatile("" : "+v"(popped));  // keep the read unconditional: sunk into a branch it splits the loop body
-        const bool pop = !any_inner && !any_leaf && t_sp > 0;
-        t_cur = any_inner ? ia : (pop ? popped : FNODE_NONE);
-        t_sp = t_sp + (both ? 1 : 0) - (pop ? 1 : 0);
+        const bool pop = !any_inner && !any_leaf && w.t_sp > 0;
+        w.t_cur = any_inner ? ia : (pop ? popped : FNODE_NONE);
+        w.t_sp = w.t_sp + (both ? 1 : 0) - (pop ? 1 : 0);
     }
 
     // ---- fast BVH: fp32 conservative boxes, fp64 triangle tests.  Meshes are taken one at a time by the whole wave
@@ -633,6 +636,9 @@ struct Tracer {
         // reciprocal direction in fp32 (1 ulp): every use below is a conservative cull, never a result
         const float ix = __builtin_amdgcn_rcpf((float)r.d.x), iy = __builtin_amdgcn_rcpf((float)r.d.y), iz = __builtin_amdgcn_rcpf((float)r.d.z);
         TIME_DECL;
+        Walk w;
+        w.stop_traversal();
+        w.t_ax = w.t_ay = w.t_az = w.t_bx = w.t_by = w.t_bz = w.t_enter = 0;
         const int n_meshes = SC.n_meshes;
         const auto meshes = as_const(SC.meshes);
         const FNode *const fnodes = SC.fnodes;
@@ -664,16 +670,16 @@ struct Tracer {
             if (__ballot(enter) == 0ull) continue;
             // shift the origin to (just before) the entry point, so that its fp32 rounding error inside the
             // traversal (2^-24 of the mesh size) is far inside the 2^-18 inflation of the boxes
-            t_enter = tn_root > 0 ? tn_root * 0.99999905f : 0.0f;
-            const double te = (double)t_enter;
+            w.t_enter = tn_root > 0 ? tn_root * 0.99999905f : 0.0f;
+            const double te = (double)w.t_enter;
             const float sx = (float)((r.o.x + te * r.d.x) - me.center[0]);
             const float sy = (float)((r.o.y + te * r.d.y) - me.center[1]);
             const float sz = (float)((r.o.z + te * r.d.z) - me.center[2]);
-            t_ax = ix; t_ay = iy; t_az = iz;
-            t_bx = -sx * ix; t_by = -sy * iy; t_bz = -sz * iz;
+            w.t_ax = ix; w.t_ay = iy; w.t_az = iz;
+            w.t_bx = -sx * ix; w.t_by = -sy * iy; w.t_bz = -sz * iz;
             float limf = f32_up(lim - te);
             const int obj = me.obj;
-            stop_traversal();
+            w.stop_traversal();
             if (enter) { LOOP_TICK(38); }
 #ifndef RAYHS_NO_PACKET
             // Coherent wave -> packet traversal.  The lanes of a wave hold samples of the same few pixels, and their rays of
@@ -708,8 +714,8 @@ struct Tracer {
                     const auto &nd = as_const(fnodes)[cur];
                     const int c0 = nd.c0, c1 = nd.c1;
                     float tn0, tn1;
-                    const bool h0 = pbox(nd.b0, t_ax, t_ay, t_az, t_bx, t_by, t_bz, limf, tn0) && live && c0 != FNODE_NONE;
-                    const bool h1 = pbox(nd.b1, t_ax, t_ay, t_az, t_bx, t_by, t_bz, limf, tn1) && live && c1 != FNODE_NONE;
+                    const bool h0 = pbox(nd.b0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0) && live && c0 != FNODE_NONE;
+                    const bool h1 = pbox(nd.b1, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn1) && live && c1 != FNODE_NONE;
                     if (COUNT && live) cnt.c[CNT_NODES] += (c0 != FNODE_NONE) + (c1 != FNODE_NONE);
                     const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
                     // the child that more of the lanes that hit something would take first
@@ -739,7 +745,7 @@ struct Tracer {
                                     admitted = reference_path_admits(SC.nodes, rec(SC.fattrs, k).leaf_node, r.o, r.d);
                                 if (admitted) {
                                     if (shadow) occ = occ || in_front(r, t, point_light, light_d2);
-                                    else if (offer(t, u, v, obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - (double)t_enter); }
+                                    else if (offer(t, u, v, obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - (double)w.t_enter); }
                                 }
                             }
                         }
@@ -757,7 +763,7 @@ struct Tracer {
                 continue;
             }
 #endif
-            if (enter) t_cur = me.froot;
+            if (enter) w.t_cur = me.froot;
             TIME_ADD(12);
             while (true) {
                 // phase 1: walk inner nodes until this lane holds a leaf (or runs out of nodes).  The body is
@@ -765,11 +771,11 @@ struct Tracer {
                 // memory round trip per visit) and both child boxes are always tested.
 #ifdef RAYHS_PROFILE_LOOPS
                 if (COUNT) {  // per pass of the while-while loop: lanes still in this traversal (32), of which holding a leaf (34)
-                    if (traversing()) { LOOP_TICK(32); }
-                    if (t_pa != FNODE_NONE) { LOOP_TICK(34); }
+                    if (w.traversing()) { LOOP_TICK(32); }
+                    if (w.t_pa != FNODE_NONE) { LOOP_TICK(34); }
                 }
 #endif
-                while (t_cur != FNODE_NONE && t_pa == FNODE_NONE) {
+                while (w.t_cur != FNODE_NONE && w.t_pa == FNODE_NONE) {
                     LOOP_TICK(10);
 #ifdef RAYHS_PROFILE_LOOPS
                     if (COUNT) cnt.c[36] += (unsigned)__popcll(__ballot(true)) < 16u;   // lane-visits made in passes with < 16 lanes active
@@ -777,23 +783,23 @@ struct Tracer {
 #endif
 #ifdef RAYHS_PROFILE_LOOPS
                     if (COUNT) {  // coherence probe: how many active lanes sit on the same node as the first active lane
-                        const int leader = __builtin_amdgcn_readfirstlane(t_cur);
-                        if (t_cur == leader) cnt.c[14]++;
-                        if (__ballot(t_cur != leader) == 0ull && (int)__lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1) cnt.c[15]++;  // wave-uniform visits
+                        const int leader = __builtin_amdgcn_readfirstlane(w.t_cur);
+                        if (w.t_cur == leader) cnt.c[14]++;
+                        if (__ballot(w.t_cur != leader) == 0ull && (int)__lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1) cnt.c[15]++;  // wave-uniform visits
                     }
 #endif
                     // Most visits are wave-uniform: the 64 lanes hold samples of the same few pixels and walk the upper tree
                     // together (55 % of the node-loop iterations on the dragon frame, 72 % at 4K / 64 spp).  Those fetch the
                     // node ONCE through the scalar cache into SGPRs; only diverged waves gather per lane.
-                    const int lead = __builtin_amdgcn_readfirstlane(t_cur);
-                    if (__ballot(t_cur != lead) == 0ull) visit(as_const(fnodes)[lead], limf);
-                    else visit(rec(fnodes, t_cur), limf);
+                    const int lead = __builtin_amdgcn_readfirstlane(w.t_cur);
+                    if (__ballot(w.t_cur != lead) == 0ull) visit(w, as_const(fnodes)[lead], limf);
+                    else visit(w, rec(fnodes, w.t_cur), limf);
                 }
                 TIME_ADD(13);
                 // phase 2: the postponed leaf, with the reference's fp64 triangle test on the ORIGINAL ray
-                if (t_pa != FNODE_NONE) {
+                if (w.t_pa != FNODE_NONE) {
                     LOOP_TICK(12);
-                    const int ref = ~t_pa;
+                    const int ref = ~w.t_pa;
                     const int first = ref >> 3, n = ref & 7;  // leaf references index the BVH-ordered arrays directly
                     for (int k = first; k < first + n; k++) {
                         const DTri tr = rec(ftris, k);
@@ -806,20 +812,20 @@ struct Tracer {
                                 admitted = reference_path_admits(SC.nodes, rec(SC.fattrs, k).leaf_node, r.o, r.d);
                             if (admitted) {
                                 if (shadow) occ = occ || in_front(r, t, point_light, light_d2);
-                                else if (offer(t, u, v, obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - (double)t_enter); }
+                                else if (offer(t, u, v, obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - (double)w.t_enter); }
                             }
                         }
                     }
-                    t_pa = t_pb;
-                    t_pb = FNODE_NONE;
-                    if (shadow && occ) stop_traversal();  // any occluder settles a shadow query
+                    w.t_pa = w.t_pb;
+                    w.t_pb = FNODE_NONE;
+                    if (shadow && occ) w.stop_traversal();  // any occluder settles a shadow query
                 }
-                if (t_pa == FNODE_NONE && t_cur == FNODE_NONE && t_sp > 0) {
-                    t_sp--;
-                    t_cur = (int)stack[t_sp * TRACE_BLOCK];
+                if (w.t_pa == FNODE_NONE && w.t_cur == FNODE_NONE && w.t_sp > 0) {
+                    w.t_sp--;
+                    w.t_cur = (int)stack[w.t_sp * TRACE_BLOCK];
                 }
                 TIME_ADD(14);
-                if (__ballot(traversing()) == 0ull) break;
+                if (__ballot(w.traversing()) == 0ull) break;
             }
         }
     }
@@ -1048,7 +1054,7 @@ static __device__ __forceinline__ void trace_body() {
                     } else {
                         const auto &s = rec(SC.spheres, -tr.bprim - 2);
                         c_n = unit(sub(c_p, ld3(s.c)));
-                        if (need_uv) polar_uv(c_n, hu, hv);  // src/Geometry.hs:96
+                        if (need_uv) { const UV2 uv = polar_uv(c_n); hu = uv.u; hv = uv.v; }  // src/Geometry.hs:96
                     }
                     // the context of the hit being shaded waits in LDS while its rays are traced
                     cx_store3(cx, CX_P, c_p); cx_store3(cx, CX_N, c_n);
