@@ -566,9 +566,10 @@ static int ensure_workspace(const rayhs_scene *s, const DParams &dp, hipStream_t
         void *p = nullptr;
         HIP_TRY(hipMalloc(&p, need));
         s->frames = (double *)p; s->frames_bytes = need;
-        // touch the fresh pages once, in stream order, in front of the first frame: its kernel otherwise pays the first
-        // touch of ~100 MB inside its own time (4-5 % of a 1080p frame, tools/first_frame.py)
-        HIP_TRY(hipMemsetAsync(p, 0, need, st));
+        // (Not touched here: a memset of the fresh ~100 MB in front of the first frame took the first-touch cost out of
+        // that frame's kernel time -- 4-5 % of a 1080p frame, tools/first_frame.py -- but cost 3.4 ms of its own, serially,
+        // where the kernel absorbs the touches it really makes in parallel: `rayhs --timing` render 7.9 -> 11.3 ms.)
+        (void)st;
     }
     // spp > 1: one radiance triple per (pixel, sample), folded in sample order by rayhs_resolve
     size_t sneed = dp.spp > 1 && !dp.wave_resolve ? (size_t)dp.n_rows * (size_t)dp.width * (size_t)dp.spp * 3 * sizeof(double) : 0;
