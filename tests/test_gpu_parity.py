@@ -721,7 +721,7 @@ def oracle_image_text(text, tmp_path, **kw):
 
 
 # ---------------------------------------------------------------------- fuzz
-def _rand_scene(rng):
+def _rand_scene(rng, more_meshes=()):
     def v(lo, hi): return {k: float(rng.uniform(lo, hi)) for k in "xyz"}
     def col(hi=1.5): return {k: float(rng.uniform(0, hi)) for k in "rgb"}
     def cmap(allow_checker):
@@ -749,7 +749,7 @@ def _rand_scene(rng):
         n = v(-1, 1)
         objs.append({"geometry": {"type": "plane", "point": v(-1.2, 1.2), "normal": n, "tangent": v(-1, 1)}, "material": material()})
     for _ in range(int(rng.integers(0, 3))):
-        f = str(rng.choice(["data/cube.obj", "data/cone.obj", "data/torus.obj", "data/uvcube.obj", "data/uvtorus.obj"]))
+        f = str(rng.choice(["data/cube.obj", "data/cone.obj", "data/torus.obj", "data/uvcube.obj", "data/uvtorus.obj"] + list(more_meshes)))
         objs.append({"geometry": {"type": "mesh", "fileName": f, "transform": xform()}, "material": material(f.startswith("data/uv"))})
     rng.shuffle(objs)
     lights = []
@@ -783,6 +783,25 @@ def test_random_scenes_bit_exact(tmp_path, seed):
         img, _ = r.ray_trace(spp=spp)
         assert ((img == want) | (np.isnan(img) & np.isnan(want))).all(), seed
     r.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RAYHS_FUZZ_SEEDS_SPP", "12"))))
+def test_random_scenes_many_samples_per_pixel_bit_exact(tmp_path, seed):
+    # the other end of the work layout: a wave holds the 64 samples of ONE pixel (spp 64), of four (16), or a count
+    # that does not divide 64 -- nearly parallel rays, the wave-uniform packet walk and the in-wave sample fold --
+    # on random scenes that may hold a 1,700-triangle mesh under a random transform
+    rng = np.random.default_rng(5000 + seed)
+    jd = _rand_scene(rng, more_meshes=("data/dragon_superlow.obj", "data/dragon_superlow.obj"))
+    spp = int(rng.choice([16, 64, 7, 96]))
+    p = tmp_path / "f.json"
+    p.write_text(json.dumps(jd))
+    want, ost = oracle_image(str(p), spp=spp)
+    for flags in (PRODUCTION, COUNTING):
+        got, st = rayhs_amd.ray_trace_file(str(p), spp=spp, flags=flags)
+        same = (got == want) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (seed, flags, np.abs(np.nan_to_num(got) - np.nan_to_num(want)).max(), int((~same).any(axis=2).sum()))
+        if flags == COUNTING:
+            assert st["rays"] == ost["rays"], seed
 
 
 def test_rays_through_mesh_vertices_and_edges(tmp_path):
