@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--workload", default="dragon", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--fma", action="store_true", help="use the fused-multiply-add kernels (not bit-exact with the reference)")
+    ap.add_argument("--no-4k", dest="also_4k", action="store_false",
+                    help="skip the extra (untimed for `value`) leg on BASELINE configs[4], the 4K / 64 spp frame")
     ap.add_argument("--verify", action="store_true",
                     help="rank 0 also renders the whole frame by itself and checks that the gathered frame is identical")
     args = ap.parse_args()
@@ -172,108 +174,140 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    scene, spp, desc = WORKLOADS[args.workload]
-    rd = RenderDesc(scene)
-    # Two frames in flight: each slot has its own scene handle (13 MB of HBM, its own launch workspace and tile order),
-    # its own stream and its own gather buffers.  A persistent kernel ends with its slowest wave, so the last part of
-    # frame i leaves most of the chip idle; frame i + 1, enqueued on the other stream, starts in those idle CUs, and the
-    # gather of frame i (RCCL's stream) runs beside it.  (tools/overlap_frames.py, per frame: a 1/8 share of the 1080p
-    # frame 1.39 ms alone, 1.08 with two in flight; the whole frame 7.62 -> 7.58 ms.  Three in flight: 0.98 ms for the
-    # share in that tool, but in this loop the whole frame gets slower, 7.57 -> 7.8 ms: two trace kernels then run
-    # side by side for most of their time instead of tail to head.)
-    renderings = [Rendering(rd, device=local_rank) for _ in range(IN_FLIGHT)]
-    r = renderings[0]
-    w, h = r.width, r.height
-    slots = [tiles.FrameGather(rank, world, h, w, STRIPE_ROWS, dev, torch.float32) for _ in range(IN_FLIGHT)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(IN_FLIGHT)]
-    g = slots[0]
-    flags = L.FLAG_FMA if args.fma else 0
-    kw = dict(spp=spp, seed=24, stripe_rows=STRIPE_ROWS, stripe_rank=rank, stripe_count=world, out_format=L.OUT_F32)
-    stream = torch.cuda.current_stream()
+    def run_workload(workload, steps, warmup, want_first_frame=True):
+        """Set-up, warm-up and the timed loop of one workload; returns its local variables."""
+        scene, spp, desc = WORKLOADS[workload]
+        rd = RenderDesc(scene)
+        # Two frames in flight: each slot has its own scene handle (13 MB of HBM, its own launch workspace and tile order),
+        # its own stream and its own gather buffers.  A persistent kernel ends with its slowest wave, so the last part of
+        # frame i leaves most of the chip idle; frame i + 1, enqueued on the other stream, starts in those idle CUs, and the
+        # gather of frame i (RCCL's stream) runs beside it.  (tools/overlap_frames.py, per frame: a 1/8 share of the 1080p
+        # frame 1.39 ms alone, 1.08 with two in flight; the whole frame 7.62 -> 7.58 ms.  Three in flight: 0.98 ms for the
+        # share in that tool, but in this loop the whole frame gets slower, 7.57 -> 7.8 ms: two trace kernels then run
+        # side by side for most of their time instead of tail to head.)
+        renderings = [Rendering(rd, device=local_rank) for _ in range(IN_FLIGHT)]
+        r = renderings[0]
+        w, h = r.width, r.height
+        slots = [tiles.FrameGather(rank, world, h, w, STRIPE_ROWS, dev, torch.float32) for _ in range(IN_FLIGHT)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(IN_FLIGHT)]
+        g = slots[0]
+        flags = L.FLAG_FMA if args.fma else 0
+        kw = dict(spp=spp, seed=24, stripe_rows=STRIPE_ROWS, stripe_rank=rank, stripe_count=world, out_format=L.OUT_F32)
+        stream = torch.cuda.current_stream()
 
-    pending = []
+        pending = []
 
-    def step(i, ev=None):
-        j = i % IN_FLIGHT
-        cur = slots[j]
-        with torch.cuda.stream(streams[j]):  # the collective waits for, and the assembly runs on, the slot's stream
-            # the library records the two HIP events on the stream right around the trace kernel itself
-            renderings[j].ray_trace_device(cur.local.data_ptr(), streams[j].cuda_stream, flags=flags,
-                                           events=(ev[0].cuda_event, ev[1].cuda_event) if ev else None, **kw)
-            cur.gather_start()
-        pending.append((j, cur))
-        if len(pending) == IN_FLIGHT:  # the oldest frame in flight: its transfer ran beside the traces enqueued since
-            k, prev = pending.pop(0)
-            with torch.cuda.stream(streams[k]):
-                prev.gather_finish()
+        def step(i, ev=None):
+            j = i % IN_FLIGHT
+            cur = slots[j]
+            with torch.cuda.stream(streams[j]):  # the collective waits for, and the assembly runs on, the slot's stream
+                # the library records the two HIP events on the stream right around the trace kernel itself
+                renderings[j].ray_trace_device(cur.local.data_ptr(), streams[j].cuda_stream, flags=flags,
+                                               events=(ev[0].cuda_event, ev[1].cuda_event) if ev else None, **kw)
+                cur.gather_start()
+            pending.append((j, cur))
+            if len(pending) == IN_FLIGHT:  # the oldest frame in flight: its transfer ran beside the traces enqueued since
+                k, prev = pending.pop(0)
+                with torch.cuda.stream(streams[k]):
+                    prev.gather_finish()
 
-    def drain():
-        while pending:
-            k, prev = pending.pop(0)
-            with torch.cuda.stream(streams[k]):
-                prev.gather_finish()
+        def drain():
+            while pending:
+                k, prev = pending.pop(0)
+                with torch.cuda.stream(streams[k]):
+                    prev.gather_finish()
 
-    def sync_all():
+        def sync_all():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        # one instrumented (untimed) run of the same kernel: rays and algorithmic bytes of a frame
+        counters = torch.zeros(16, dtype=torch.int64, device=dev)
+        r.ray_trace_device(g.local.data_ptr(), stream.cuda_stream, counters.data_ptr(), flags=flags | L.FLAG_COUNT, **kw)
         torch.cuda.synchronize()
+        names = ["rays_primary", "rays_reflect", "rays_refract", "rays_refract_exit", "rays_shadow", "nodes_tested", "tris_tested",
+                 "prims_tested", "shaded_hits", "pixels", "shadow_skipped"]
+        counters[9] //= spp  # the kernel counts finished samples; pixels = samples / spp
+        mine = dict(zip(names, counters[:11].tolist()))
+        total = counters.clone()
         if world > 1:
-            dist.barrier()
+            dist.all_reduce(total)
+        tot = dict(zip(names, total[:11].tolist()))
+        # rays_* count the REFERENCE's scene queries of the frame; shadow queries whose light term is exactly zero are not
+        # traced at all (trace_kernel.hip, light section) and are NOT counted in `value`
+        reference_rays_frame = sum(v for k, v in tot.items() if k.startswith("rays_"))
+        rays_frame = reference_rays_frame - tot["shadow_skipped"]
+
+        # set-up, like the instrumented run above: the first frame a scene handle renders runs in scan order and measures
+        # the chunk times that order every later frame (DESIGN.md section 4); the warm-up and timed steps are steady state
+        for j in range(IN_FLIGHT):
+            renderings[j].ray_trace_device(slots[j].local.data_ptr(), streams[j].cuda_stream, flags=flags, **kw)
+            torch.cuda.synchronize()
+        for i in range(warmup):
+            step(i)
+        drain()
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for i, (a, b) in enumerate(events):  # torch creates the underlying hipEvent lazily, on first record
+            a.record(streams[i % IN_FLIGHT])
+            b.record(streams[i % IN_FLIGHT])
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i, events[i])
+        drain()  # every frame is gathered and assembled inside the timed region
+        sync_all()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+
+        # The first frame of a handle -- the only frame a one-shot `rayhs -oX scene.json` ever renders (src/RayHs.hs:215-234)
+        # -- has no measured chunk times to order its tiles by and uses the static estimate instead.  Timed (untimed for
+        # `value`) on a FRESH handle now that the kernel's code is resident and the clocks are up: first_frame_ms is the
+        # scheduling effect alone.
+        first_frame_ms = None
+        if not want_first_frame:
+            return locals()
+        fresh = Rendering(rd, device=local_rank)
+        ff = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        for e in ff:
+            e.record(streams[0])
         torch.cuda.synchronize()
-
-    # one instrumented (untimed) run of the same kernel: rays and algorithmic bytes of a frame
-    counters = torch.zeros(16, dtype=torch.int64, device=dev)
-    r.ray_trace_device(g.local.data_ptr(), stream.cuda_stream, counters.data_ptr(), flags=flags | L.FLAG_COUNT, **kw)
-    torch.cuda.synchronize()
-    names = ["rays_primary", "rays_reflect", "rays_refract", "rays_refract_exit", "rays_shadow", "nodes_tested", "tris_tested",
-             "prims_tested", "shaded_hits", "pixels", "shadow_skipped"]
-    counters[9] //= spp  # the kernel counts finished samples; pixels = samples / spp
-    mine = dict(zip(names, counters[:11].tolist()))
-    total = counters.clone()
-    if world > 1:
-        dist.all_reduce(total)
-    tot = dict(zip(names, total[:11].tolist()))
-    # rays_* count the REFERENCE's scene queries of the frame; shadow queries whose light term is exactly zero are not
-    # traced at all (trace_kernel.hip, light section) and are NOT counted in `value`
-    reference_rays_frame = sum(v for k, v in tot.items() if k.startswith("rays_"))
-    rays_frame = reference_rays_frame - tot["shadow_skipped"]
-
-    # set-up, like the instrumented run above: the first frame a scene handle renders runs in scan order and measures
-    # the chunk times that order every later frame; the warm-up and timed steps are steady state
-    for j in range(IN_FLIGHT):
-        renderings[j].ray_trace_device(slots[j].local.data_ptr(), streams[j].cuda_stream, flags=flags, **kw)
+        fresh.ray_trace_device(slots[0].local.data_ptr(), streams[0].cuda_stream, flags=flags, events=(ff[0].cuda_event, ff[1].cuda_event), **kw)
         torch.cuda.synchronize()
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for i, (a, b) in enumerate(events):  # torch creates the underlying hipEvent lazily, on first record
-        a.record(streams[i % IN_FLIGHT])
-        b.record(streams[i % IN_FLIGHT])
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, events[i])
-    drain()  # every frame is gathered and assembled inside the timed region
-    sync_all()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+        first_frame_ms = ff[0].elapsed_time(ff[1])
+        fresh.close()
+        return locals()
 
-    # The first frame of a handle -- the only frame a one-shot `rayhs -oX scene.json` ever renders (src/RayHs.hs:215-234)
-    # -- has no measured chunk times to order its tiles by and uses the static estimate instead.  Timed (untimed for
-    # `value`) on a FRESH handle now that the kernel's code is resident and the clocks are up: first_frame_ms is the
-    # scheduling effect alone.
-    fresh = Rendering(rd, device=local_rank)
-    ff = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    for e in ff:
-        e.record(streams[0])
-    torch.cuda.synchronize()
-    fresh.ray_trace_device(slots[0].local.data_ptr(), streams[0].cuda_stream, flags=flags, events=(ff[0].cuda_event, ff[1].cuda_event), **kw)
-    torch.cuda.synchronize()
-    first_frame_ms = ff[0].elapsed_time(ff[1])
-    fresh.close()
+    m = run_workload(args.workload, args.steps, args.warmup)
+    scene, spp, desc, r, w, h, slots, stream = m["scene"], m["spp"], m["desc"], m["r"], m["w"], m["h"], m["slots"], m["stream"]
+    mine, rays_frame, reference_rays_frame = m["mine"], m["rays_frame"], m["reference_rays_frame"]
+    dt, kernel_ms, first_frame_ms, flags = m["dt"], m["kernel_ms"], m["first_frame_ms"], m["flags"]
+
+    # north_star quotes its 1 -> 8 GPU scaling target on the 4K tile-sharded render (BASELINE configs[4]); the headline
+    # `value` stays on configs[3].  The same loop on that frame, a few steps, every rank taking part: lets the driver's
+    # scaling run show both frames.  Not part of `value`, `ms_per_step` or the roofline.
+    also_4k, launches_after_timed = None, 1 + (1 if args.verify else 0)
+    if args.also_4k and args.workload != "dragon4k":
+        x = run_workload("dragon4k", 3, 1, want_first_frame=False)
+        launches_after_timed += IN_FLIGHT + 1 + 3
+        if rank == 0:
+            import hashlib
+            f4 = x["slots"][(3 - 1) % IN_FLIGHT].frame
+            want4 = None if args.fma else golden_digest("dragon4k")
+            ok4 = None if want4 is None else hashlib.sha256(f4.cpu().numpy().tobytes()).hexdigest() == want4
+            if ok4 is False:
+                raise SystemExit("bench.py: the 4K frame differs from the oracle's frame digest (tests/golden/frame_digests.json)")
+            also_4k = {"workload": x["desc"], "steps": 3, "warmup": 1, "ms_per_step": x["dt"] / 3 * 1e3, "kernel_ms_rank0": x["kernel_ms"],
+                       "value": x["rays_frame"] * 3 / x["dt"] / 1e6, "unit": "Mrays/s", "rays_per_frame": x["rays_frame"],
+                       "whole_frame_sha256_equals_oracle_digest": ok4}
+        for q in x["renderings"]:
+            q.close()
+        del x
 
     if rank == 0:
         frame = slots[(args.steps - 1) % IN_FLIGHT].frame
@@ -321,6 +355,7 @@ def main():
             "mpixels_per_s": w * h * args.steps / dt / 1e6,
             "rays_per_frame": rays_frame, "reference_rays_per_frame": reference_rays_frame,
             "kernel_ms_rank0": kernel_ms, "first_frame_ms": first_frame_ms,
+            "north_star_4k": also_4k, "trace_launches_after_timed": launches_after_timed,
             "verified_against_single_rank": verified,
             "verified_against_oracle": {"whole_frame_sha256_equals_oracle_digest": golden_ok, "rows_against_live_oracle": None},
             "roofline": roofline,

@@ -570,6 +570,9 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert out["n_gpus"] == 2 and out["verified_against_single_rank"] is True
     assert out["metric"] == "Mrays/s" and out["value"] > 0 and out["scaling"] == "strong"
     assert out["rays_per_frame"] > 1920 * 1080 * 4
+    # the extra leg on the 4K / 64 spp frame (BASELINE configs[4]): two ranks' stripes gathered, whole frame == oracle digest
+    k4 = out["north_star_4k"]
+    assert k4["whole_frame_sha256_equals_oracle_digest"] is True and k4["ms_per_step"] > 0 and k4["rays_per_frame"] > 3840 * 2160 * 64
 
 
 def test_timed_entry_point_records_events_around_the_trace_kernel():

@@ -16,8 +16,8 @@ mkdir -p $out
 steps=30; [ "$wl" = dragon4k ] && steps=8
 sha256sum rayhs_amd/csrc/trace_kernel.hip rayhs_amd/csrc/device_scene.h rayhs_amd/csrc/abi.cpp | sha256sum | cut -d' ' -f1 > ${pre}_kernel_source.sha256
 timeout -k 10 500 python3 bench.py --workload $wl --steps $steps --warmup 3 > ${pre}_bench.json 2> ${pre}_bench.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d ${pre}_trace -- python3 bench.py --workload $wl --steps $steps --warmup 3 --cpu-seconds 0 > ${pre}_trace_bench.json 2>/dev/null || exit 2
-pmc() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d ${pre}_pmc_$name -- python3 bench.py --workload $wl --steps 3 --warmup 1 --cpu-seconds 0 > /dev/null 2>&1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d ${pre}_trace -- python3 bench.py --workload $wl --steps $steps --warmup 3 --cpu-seconds 0 --no-4k > ${pre}_trace_bench.json 2>/dev/null || exit 2
+pmc() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d ${pre}_pmc_$name -- python3 bench.py --workload $wl --steps 3 --warmup 1 --cpu-seconds 0 --no-4k > /dev/null 2>&1; }
 pmc fetch FETCH_SIZE || exit 3
 pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum || exit 4
 pmc sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU || exit 5

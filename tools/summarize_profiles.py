@@ -40,8 +40,9 @@ for f in newest(f"{pre}_trace/*/*_kernel_trace.csv"):
         tb = {}
     steps = tb.get("steps", 0)
     rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("rayhs_trace") and "count" not in r["Kernel_Name"]]
-    if steps and len(rows) >= steps:
-        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows[-steps:]]
+    after = tb.get("trace_launches_after_timed", 1 if tb.get("first_frame_ms") is not None else 0)  # the first-frame launch on a fresh handle (and --verify / the 4K leg) follow the timed loop
+    if steps and len(rows) >= steps + after:
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows[len(rows) - after - steps:len(rows) - after]]
         out["timed_launches"] = {"kernel": rows[-1]["Kernel_Name"], "launches": steps, "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d),
                                  "bench_events_avg_ms": tb.get("kernel_ms_rank0"), "first_frame_ms": tb.get("first_frame_ms")}
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
