@@ -351,8 +351,8 @@ struct Tracer {
             num = dot(pn, sub(pp, r.o));
         }
     }
-    static __device__ __forceinline__ bool quotient_may_be_positive(double num, double den) {
-        return (num > 0 && den > 0) || (num < 0 && den < 0);
+    static __device__ __forceinline__ unsigned long long quotient_may_be_positive(double num, double den) {  // wave mask
+        return (__ballot(num > 0) & __ballot(den > 0)) | (__ballot(num < 0) & __ballot(den < 0));
     }
     // Sphere (src/Geometry.hs:78-85): the discriminant first; the roots (a square root and two divisions) only when
     // some lane of the wave has delta >= 0.
@@ -362,16 +362,15 @@ struct Tracer {
         double c = dot(oc, oc) - s.r2;
         delta = b * b - 4.0 * a * c;
     }
-    static __device__ __forceinline__ bool sphere_roots(double a, double b, double delta, double &t) {
+    static __device__ __forceinline__ unsigned long long sphere_roots(double a, double b, double delta, double &t) {  // wave mask of hits
         // guards of src/Geometry.hs:81-85 in order: delta < 0 -> miss; t0 > 0 -> t0; t1 > 0 -> t1; else miss.
         // Both roots are formed without branching (a NaN from sqrt of a negative delta is masked by the guard).
         double sq = sqrt(delta);
         double t0 = 0.5 * ((-b) - sq) / a;
         double t1 = 0.5 * ((-b) + sq) / a;
-        const bool ok = !(delta < 0.0);
-        const bool use0 = t0 > 0, use1 = t1 > 0;
+        const bool use0 = t0 > 0;
         t = use0 ? t0 : t1;
-        return ok && (use0 || use1);
+        return ~__ballot(delta < 0.0) & (__ballot(t0 > 0) | __ballot(t1 > 0));
     }
 
     // rayInterBox (src/KDTree.hs:39-56); returns pass and tmin
@@ -433,6 +432,17 @@ struct Tracer {
         return tf >= fmaxf(tn, 0.0f) && tn <= limf;
     }
 
+    // the same test as a wave mask (each ballot is of one comparison, which then writes the mask itself)
+    template <class BP> __device__ __forceinline__ unsigned long long pbox_mask(BP b, float ax, float ay, float az, float bx, float by, float bz, float limf, float &tnear) {
+        const f2 x = __builtin_elementwise_fma((f2){b[0], b[1]}, (f2){ax, ax}, (f2){bx, bx});
+        const f2 y = __builtin_elementwise_fma((f2){b[2], b[3]}, (f2){ay, ay}, (f2){by, by});
+        const f2 z = __builtin_elementwise_fma((f2){b[4], b[5]}, (f2){az, az}, (f2){bz, bz});
+        float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fminf(z.x, z.y));
+        float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fmaxf(z.x, z.y));
+        tnear = tn;
+        return __ballot(tf >= fmaxf(tn, 0.0f)) & __ballot(tn <= limf);
+    }
+
     // conservative fp32 slab test of the mesh bounds (root cull); t is relative to the given origin
     __device__ __forceinline__ bool fbox(const float *lo, const float *hi, float ox, float oy, float oz, float ix, float iy, float iz,
                                          float limf, float &tnear) {
@@ -453,15 +463,20 @@ struct Tracer {
     __device__ void begin(int kind, const Ray &r, bool point_light, double light_d2) {
         const bool active = kind != Q_NONE;
         const bool shadow = kind == Q_SHADOW;
-        bool occluded = false;
         if (active) { bt = __builtin_inf(); bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; }
         armed = false;
 
-        // ---- planes and spheres: wave-uniform loops, scene constants via scalar loads.  The per-lane
-        // decisions are predicated selects, and the only branches are wave-level (ballot): nested per-lane
-        // ifs cost more scalar exec-mask bookkeeping here than the arithmetic they guard.
-        const unsigned long long wave_active = __ballot(active);
-        const unsigned long long wave_shadow = __ballot(active && shadow);
+        // ---- planes and spheres: wave-uniform loops, scene constants via scalar loads.  Every per-lane yes/no of
+        // these loops is a 64-bit WAVE MASK in scalar registers (lane i = bit i), combined with scalar logic and turned
+        // back into a lane predicate only where a select needs one (inverse_ballot: the mask IS the select's condition).
+        // As `bool` variables they were kept as 0/1 in vector registers across the loop and re-compared at every use:
+        // a dozen vector instructions of bookkeeping per plane beside ~20 of arithmetic.  The only branches are
+        // wave-level: nested per-lane ifs cost more scalar exec-mask bookkeeping than the arithmetic they guard.
+        typedef unsigned long long mask_t;
+        const mask_t m_active = __ballot(active);
+        const mask_t m_shadow = __ballot(active && shadow);
+        const mask_t m_point = __ballot(active && shadow && point_light);  // shadow queries towards a point light
+        mask_t m_occ = 0;  // lanes whose shadow query has found an occluder
         const double a = dot(r.d, r.d);
         const double o_max = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z));
         const double o_guard = (o_max * o_max) * 1e-18;
@@ -480,33 +495,41 @@ struct Tracer {
             if (AXIS < 3) { nk = rec_.nk; pk = rec_.pk; asm volatile("" :: "s"(pl_obj), "s"(pl_occluder), "s"(nk), "s"(pk)); }
             else { pn = ld3(rec_.n); pp = ld3(rec_.p); asm volatile("" :: "s"(pl_obj), "s"(pl_occluder), "s"(pn.x), "s"(pn.y), "s"(pn.z), "s"(pp.x), "s"(pp.y), "s"(pp.z)); }
             // outside the exhaustive kernels a shadow query skips Emmit objects and stops at its first occluder
-            const bool consider = active && (EXH || !(shadow && (occluded || !pl_occluder)));
-            if (COUNT && consider) cnt.c[CNT_PRIMS]++;
-            if (consider) { LOOP_TICK(18); }
+            const mask_t m_consider = EXH ? m_active : (m_active & ~(m_shadow & (pl_occluder ? m_occ : ~0ull)));
+            if (COUNT) cnt.c[CNT_PRIMS] += __builtin_amdgcn_inverse_ballot_w64(m_consider) ? 1 : 0;
+            if (__builtin_amdgcn_inverse_ballot_w64(m_consider)) { LOOP_TICK(18); }
             double num, den;
             plane_terms<AXIS>(nk, pk, pn, pp, r, num, den);
             // a shadow query only asks whether the hit lies in front of the light: with an approximate quotient
             // (v_rcp_f64, ~1e-8) a plane whose squared hit distance exceeds the light's by more than 1e-4 of it is
             // settled without the division.  (in_front forms |o - (o + t d)|^2; its cancellation error stays
             // below that margin unless the origin is 1e9 hit distances away from zero -- then we divide.)
-            const double q = num * __builtin_amdgcn_rcp(den);
-            const double s_far = (q * q) * a;
-            const bool beyond_light = shadow && point_light && s_far * (1.0 - 1e-4) > light_d2 && s_far > o_guard;
-            const bool wanted = consider && quotient_may_be_positive(num, den) && !beyond_light;
-            // one wave-level branch per plane: everything above is straight-line and predicated (the loop ran six
-            // conditional branches per plane before, and they cost more than the arithmetic they skipped)
-            if (__ballot(wanted) != 0ull) {
-                if (wanted) { LOOP_TICK(20); }
+            mask_t m_beyond = 0;
+            if (m_point != 0ull) {
+                const double q = num * __builtin_amdgcn_rcp(den);
+                const double s_far = (q * q) * a;
+                m_beyond = m_point & __ballot(s_far * (1.0 - 1e-4) > light_d2) & __ballot(s_far > o_guard);
+            }
+            // (every ballot is of ONE comparison: the compare then writes the mask itself; a ballot of `a && b` goes through
+            // a 0/1 vector register)
+            const mask_t m_wanted = m_consider & ~m_beyond & quotient_may_be_positive(num, den);
+            // one wave-level branch per plane: everything above is straight-line (the loop ran six conditional branches
+            // per plane before, and they cost more than the arithmetic they skipped)
+            if (m_wanted != 0ull) {
+                if (__builtin_amdgcn_inverse_ballot_w64(m_wanted)) { LOOP_TICK(20); }
                 const double t = num / den;
-                const bool hit = consider && fabs(den) > 0 && t > 0;
-                const bool front = in_front(r, t, point_light, light_d2);
-                occluded = occluded || (hit && shadow && pl_occluder != 0 && front);
-                const bool better = hit && !shadow && (t < bt || (t == bt && pl_obj < bobj));
+                const mask_t m_hit = m_consider & __ballot(fabs(den) > 0) & __ballot(t > 0);
+                if (pl_occluder != 0 && (m_hit & m_shadow) != 0ull) {
+                    // (in_front is true for every directional light)
+                    m_occ |= m_hit & m_shadow & (~m_point | __ballot(in_front(r, t, true, light_d2)));
+                }
+                const mask_t m_better = m_hit & ~m_shadow & (__ballot(t < bt) | (__ballot(t == bt) & __ballot(pl_obj < bobj)));
+                const bool better = __builtin_amdgcn_inverse_ballot_w64(m_better);
                 bt = better ? t : bt; bobj = better ? pl_obj : bobj; bprim = better ? i : bprim;
             }
             }
         };
-        if (wave_active != 0ull) {
+        if (m_active != 0ull) {
             // a ray with a non-finite component (0 * inf = NaN in the reference's sums) forces the general form on everyone
             const bool all_finite = __ballot(active && !isfinite(((r.d.x + r.d.y) + r.d.z) + ((r.o.x + r.o.y) + r.o.z))) == 0ull;
             const int ex = all_finite ? SC.plane_axis_end[0] : 0, ey = all_finite ? SC.plane_axis_end[1] : 0, ez = all_finite ? SC.plane_axis_end[2] : 0;
@@ -516,26 +539,26 @@ struct Tracer {
             plane_range(std::integral_constant<int, 3>(), ez, n_planes);
         }
         const auto spheres = as_const(SC.spheres);
-        for (int i = 0; i < n_spheres && wave_active != 0ull; i++) {
+        for (int i = 0; i < n_spheres && m_active != 0ull; i++) {
             // (one batch of scalar loads per sphere, as for the planes)
             struct { double c[3], r2; int obj, occluder; } s;
             { const auto &q = spheres[i]; s.c[0] = q.c[0]; s.c[1] = q.c[1]; s.c[2] = q.c[2]; s.r2 = q.r2; s.obj = q.obj; s.occluder = q.occluder; }
             asm volatile("" :: "s"(s.c[0]), "s"(s.c[1]), "s"(s.c[2]), "s"(s.r2), "s"(s.obj), "s"(s.occluder));
-            const bool consider = active && (EXH || !(shadow && (occluded || !s.occluder)));
-            if (__ballot(consider) == 0ull) continue;
-            if (COUNT && consider) cnt.c[CNT_PRIMS]++;
-            if (consider) { LOOP_TICK(22); }
+            const mask_t m_consider = EXH ? m_active : (m_active & ~(m_shadow & (s.occluder ? m_occ : ~0ull)));
+            if (m_consider == 0ull) continue;
+            if (COUNT) cnt.c[CNT_PRIMS] += __builtin_amdgcn_inverse_ballot_w64(m_consider) ? 1 : 0;
+            if (__builtin_amdgcn_inverse_ballot_w64(m_consider)) { LOOP_TICK(22); }
             double b, delta, t = 0;
             sphere_terms(s, r, a, b, delta);
-            if (__ballot(consider && !(delta < 0.0)) == 0ull) continue;
-            const bool hit = sphere_roots(a, b, delta, t) && consider;
-            if (wave_shadow != 0ull && __ballot(hit && shadow) != 0ull) {
-                const bool front = in_front(r, t, point_light, light_d2);
-                occluded = occluded || (hit && shadow && s.occluder != 0 && front);
-            }
-            const bool better = hit && !shadow && (t < bt || (t == bt && s.obj < bobj));
+            if ((m_consider & ~__ballot(delta < 0.0)) == 0ull) continue;
+            const mask_t m_hit = m_consider & sphere_roots(a, b, delta, t);
+            if (s.occluder != 0 && (m_hit & m_shadow) != 0ull)
+                m_occ |= m_hit & m_shadow & (~m_point | __ballot(in_front(r, t, true, light_d2)));
+            const mask_t m_better = m_hit & ~m_shadow & (__ballot(t < bt) | (__ballot(t == bt) & __ballot(s.obj < bobj)));
+            const bool better = __builtin_amdgcn_inverse_ballot_w64(m_better);
             bt = better ? t : bt; bobj = better ? s.obj : bobj; bprim = better ? -(i + 2) : bprim;
         }
+        bool occluded = __builtin_amdgcn_inverse_ballot_w64(m_occ);
         if (n_meshes > 0) {
             // The reference's slab test multiplies by 1/d: with a zero direction component and a box plane
             // through the origin it computes 0 * inf = NaN and may reject a box the ray does touch
@@ -667,7 +690,8 @@ struct Tracer {
             float tn_root;
             if (COUNT && want) cnt.c[CNT_NODES]++;
             const bool enter = fbox(lo, hi, cxo, cyo, czo, ix, iy, iz, f32_up(lim), tn_root) && want;
-            if (__ballot(enter) == 0ull) continue;
+            const unsigned long long em = __ballot(enter);  // lanes that enter this mesh
+            if (em == 0ull) continue;
             // shift the origin to (just before) the entry point, so that its fp32 rounding error inside the
             // traversal (2^-24 of the mesh size) is far inside the 2^-18 inflation of the boxes
             w.t_enter = tn_root > 0 ? tn_root * 0.99999905f : 0.0f;
@@ -692,47 +716,55 @@ struct Tracer {
             // ends when its last lane is done, after about as many visits as its longest ray needed.  Boxes only cull, the
             // triangle tests and the tie rule are the per-lane path's, so the answer is the same.  Waves whose rays
             // neither share an octant nor form a narrow cone (reflections off the model) keep the per-lane walk below.
-            const unsigned long long em = __ballot(enter);
-            const unsigned long long nx = __ballot(enter && ix < 0.0f), ny = __ballot(enter && iy < 0.0f), nz = __ballot(enter && iz < 0.0f);
+            const unsigned long long nx = em & __ballot(ix < 0.0f), ny = em & __ballot(iy < 0.0f), nz = em & __ballot(iz < 0.0f);
 #ifdef RAYHS_PACKET_ALWAYS
             if (true) {
 #else
             // ... or into a narrow cone (within ~25 degrees) around the first entering ray's direction: shadow rays
-            // converging on a near light straddle an axis without being any less of a bundle
+            // converging on a near light straddle an axis without being any less of a bundle.  (Looking at the cone only
+            // when the octants disagree saved its twenty vector instructions for most waves and gained nothing.)
             const int lead_lane = __ffsll((unsigned long long)em) - 1;
             const float dx = (float)r.d.x, dy = (float)r.d.y, dz = (float)r.d.z;
             const float lx = __shfl(dx, lead_lane), ly = __shfl(dy, lead_lane), lz = __shfl(dz, lead_lane);
             const float cosine = (dx * lx + dy * ly + dz * lz) * __builtin_amdgcn_rsqf((dx * dx + dy * dy + dz * dz) * (lx * lx + ly * ly + lz * lz));
-            const bool cone = __ballot(enter && !(cosine > 0.9f)) == 0ull;
+            const bool cone = (em & ~__ballot(cosine > 0.9f)) == 0ull;
             if (cone || ((nx == 0ull || nx == em) && (ny == 0ull || ny == em) && (nz == 0ull || nz == em))) {
 #endif
                 const stack_ptr wstack = stack - (int)(__lane_id());  // lane 0's column serves as the wave's stack
-                bool live = enter;
+                // (lane yes/no values are wave masks in scalar registers, as in begin())
+                unsigned long long m_live = em;
+                unsigned long long m_occ = __ballot(occ);
+                const unsigned long long m_shadow_lanes = __ballot(shadow);
+                // (Requesting the next node's record before the leaves of the current visit are tested -- the scalar-cache round
+                // trip beside the triangle tests instead of after them -- was tried: the second record's 16 scalar registers on
+                // top of a triangle's 18 spilled 60 more SGPRs into vector lanes, 5.37 -> 5.90 ms.)
                 int cur = me.froot, sp = 0;
                 while (true) {
                     LOOP_TICK(40);
                     const auto &nd = as_const(fnodes)[cur];
                     const int c0 = nd.c0, c1 = nd.c1;
                     float tn0, tn1;
-                    const bool h0 = pbox(nd.b0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0) && live && c0 != FNODE_NONE;
-                    const bool h1 = pbox(nd.b1, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn1) && live && c1 != FNODE_NONE;
-                    if (COUNT && live) cnt.c[CNT_NODES] += (c0 != FNODE_NONE) + (c1 != FNODE_NONE);
-                    const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+                    const unsigned long long b0 = pbox_mask(nd.b0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0);
+                    const unsigned long long b1 = pbox_mask(nd.b1, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn1);
+                    const unsigned long long m0 = c0 != FNODE_NONE ? (b0 & m_live) : 0ull, m1 = c1 != FNODE_NONE ? (b1 & m_live) : 0ull;
+                    if (COUNT) cnt.c[CNT_NODES] += __builtin_amdgcn_inverse_ballot_w64(m_live) ? (c0 != FNODE_NONE) + (c1 != FNODE_NONE) : 0;
                     // the child that more of the lanes that hit something would take first
-                    const unsigned long long pref0 = __ballot(h0 && (!h1 || tn0 <= tn1));
-                    const bool first0 = __popcll(pref0) >= __popcll((m0 | m1) & ~pref0);
+                    const unsigned long long pref0 = m0 & (~m1 | __ballot(tn0 <= tn1));
+                    const bool first0 = (int)__popcll(pref0) >= (int)__popcll((m0 | m1) & ~pref0);
                     int next = FNODE_NONE;
                     for (int side = 0; side < 2; side++) {
                         const bool zero = (side == 0) == first0;
                         const int c = zero ? c0 : c1;
-                        if ((zero ? m0 : m1) == 0ull) continue;
+                        const unsigned long long m_side = zero ? m0 : m1;
+                        if (m_side == 0ull) continue;
                         if (c >= 0) {  // inner child: walk it next, or after the first one
                             if (next == FNODE_NONE) next = c;
                             else { wstack[sp * TRACE_BLOCK] = (StackT)c; sp++; }
                             continue;
                         }
                         // leaf: its (<= 3) triangles, each fetched once for the wave; the reference's fp64 test on the ORIGINAL ray
-                        const bool mine = (zero ? h0 : h1) && live;
+                        const bool mine = __builtin_amdgcn_inverse_ballot_w64(m_side & m_live);
+                        bool leaf_occ = false;  // per lane; folded into the mask OUTSIDE the divergent region below (a mask updated inside one stops being wave-uniform for the compiler, and all the mask logic turns into vector code)
                         const int ref = ~c, first = ref >> 3, n = ref & 7;
                         for (int k = first; k < first + n; k++) {
                             const auto &tr = as_const(ftris)[k];
@@ -744,12 +776,13 @@ struct Tracer {
                                 if (u < kEdgeBand || v < kEdgeBand || (u + v) > 1 - kEdgeBand)
                                     admitted = reference_path_admits(SC.nodes, rec(SC.fattrs, k).leaf_node, r.o, r.d);
                                 if (admitted) {
-                                    if (shadow) occ = occ || in_front(r, t, point_light, light_d2);
+                                    if (shadow) leaf_occ = leaf_occ || in_front(r, t, point_light, light_d2);
                                     else if (offer(t, u, v, obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - (double)w.t_enter); }
                                 }
                             }
                         }
-                        if (shadow && occ) live = false;  // any occluder settles a shadow query
+                        m_occ |= __ballot(leaf_occ);
+                        m_live &= ~(m_occ & m_shadow_lanes);  // any occluder settles a shadow query
                     }
                     if (next == FNODE_NONE) {
                         if (sp == 0) break;
@@ -757,8 +790,9 @@ struct Tracer {
                         next = __builtin_amdgcn_readfirstlane((int)wstack[sp * TRACE_BLOCK]);
                     }
                     cur = next;
-                    if (__ballot(live) == 0ull) break;
+                    if (m_live == 0ull) break;
                 }
+                occ = __builtin_amdgcn_inverse_ballot_w64(m_occ);
                 TIME_ADD(13);
                 continue;
             }
