@@ -398,6 +398,22 @@ struct Tracer {
         return !(fabs(det) < kEps || u < 0 || u > 1 || v < 0 || (u + v) > 1 || t < kEps);
     }
 
+    // the same test as a wave mask, straight-line (no early exit on a small determinant: its quotients are then inf or NaN,
+    // and the determinant's own bit rejects the lane).  NaN operands make every comparison false, i.e. a hit, as in the
+    // reference and in tri_test.
+    template <class TR> __device__ __forceinline__ unsigned long long tri_test_mask(const TR &tr, const Ray &r, double &t, double &u, double &v) {
+        V3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+        V3 p = cross(r.d, e2);
+        double det = dot(e1, p);
+        double idet = 1 / det;
+        V3 t0 = sub(r.o, ld3(tr.p0));
+        u = idet * dot(t0, p);
+        V3 q = cross(t0, e1);
+        v = idet * dot(r.d, q);
+        t = idet * dot(e2, q);
+        return ~(__ballot(fabs(det) < kEps) | __ballot(u < 0) | __ballot(u > 1) | __ballot(v < 0) | __ballot((u + v) > 1) | __ballot(t < kEps));
+    }
+
     // for a point light a hit occludes iff sqrDist origin light > sqrDist origin hit (src/RayHs.hs:84-87)
     __device__ __forceinline__ bool in_front(const Ray &r, double t, bool point_light, double light_d2) {
         if (!point_light) return true;
@@ -734,7 +750,7 @@ struct Tracer {
                 // (lane yes/no values are wave masks in scalar registers, as in begin())
                 unsigned long long m_live = em;
                 unsigned long long m_occ = __ballot(occ);
-                const unsigned long long m_shadow_lanes = __ballot(shadow);
+                const unsigned long long m_shadow_lanes = __ballot(shadow), m_point_lanes = __ballot(point_light);
                 // (Requesting the next node's record before the leaves of the current visit are tested -- the scalar-cache round
                 // trip beside the triangle tests instead of after them -- was tried: the second record's 16 scalar registers on
                 // top of a triangle's 18 spilled 60 more SGPRs into vector lanes, 5.37 -> 5.90 ms.)
@@ -763,25 +779,41 @@ struct Tracer {
                             continue;
                         }
                         // leaf: its (<= 3) triangles, each fetched once for the wave; the reference's fp64 test on the ORIGINAL ray
-                        const bool mine = __builtin_amdgcn_inverse_ballot_w64(m_side & m_live);
-                        bool leaf_occ = false;  // per lane; folded into the mask OUTSIDE the divergent region below (a mask updated inside one stops being wave-uniform for the compiler, and all the mask logic turns into vector code)
+                        // (every per-lane decision below is a wave mask too: as nested per-lane ifs -- hit, edge band, admitted,
+                        // shadow or closest, the tie chain -- each triangle walked a ladder of six exec-mask levels)
+                        const unsigned long long m_mine = m_side & m_live;
+                        if (m_mine == 0ull) continue;
+                        unsigned long long m_leaf_occ = 0;
                         const int ref = ~c, first = ref >> 3, n = ref & 7;
                         for (int k = first; k < first + n; k++) {
                             const auto &tr = as_const(ftris)[k];
-                            if (COUNT && mine) cnt.c[CNT_TRIS]++;
-                            if (mine) { LOOP_TICK(30); }
+                            if (COUNT) cnt.c[CNT_TRIS] += __builtin_amdgcn_inverse_ballot_w64(m_mine) ? 1 : 0;
+                            if (__builtin_amdgcn_inverse_ballot_w64(m_mine)) { LOOP_TICK(30); }
                             double t, u, v;
-                            if (mine && tri_test(tr, r, t, u, v)) {
+                            unsigned long long m_adm = m_mine & tri_test_mask(tr, r, t, u, v);
+                            if (m_adm == 0ull) continue;
+                            const unsigned long long m_edge = m_adm & (__ballot(u < kEdgeBand) | __ballot(v < kEdgeBand) | __ballot((u + v) > 1 - kEdgeBand));
+                            if (m_edge != 0ull) {  // (one hit in a million)
                                 bool admitted = true;
-                                if (u < kEdgeBand || v < kEdgeBand || (u + v) > 1 - kEdgeBand)
-                                    admitted = reference_path_admits(SC.nodes, rec(SC.fattrs, k).leaf_node, r.o, r.d);
-                                if (admitted) {
-                                    if (shadow) leaf_occ = leaf_occ || in_front(r, t, point_light, light_d2);
-                                    else if (offer(t, u, v, obj, k, tr.leaf_first, tr.rank)) { bref = false; limf = f32_up(bt - (double)w.t_enter); }
-                                }
+                                if (__builtin_amdgcn_inverse_ballot_w64(m_edge)) admitted = reference_path_admits(SC.nodes, rec(SC.fattrs, k).leaf_node, r.o, r.d);
+                                m_adm &= __ballot(admitted);
+                            }
+                            const unsigned long long m_sh = m_adm & m_shadow_lanes;
+                            if (m_sh != 0ull) m_leaf_occ |= m_sh & (~m_point_lanes | __ballot(in_front(r, t, true, light_d2)));
+                            const unsigned long long m_cl = m_adm & ~m_shadow_lanes;
+                            if (m_cl != 0ull) {
+                                // offer(): smaller t; at an exact tie the first object, the right-most leaf, the first triangle of a leaf
+                                unsigned long long m_take = __ballot(t < bt);
+                                const unsigned long long m_eq = m_cl & __ballot(t == bt);
+                                if (m_eq != 0ull)
+                                    m_take |= m_eq & (__ballot(obj < bobj) | (__ballot(obj == bobj) & (__ballot(tr.leaf_first > bleaf) | (__ballot(tr.leaf_first == bleaf) & __ballot(tr.rank < brank)))));
+                                const bool take = __builtin_amdgcn_inverse_ballot_w64(m_take & m_cl);
+                                bt = take ? t : bt; bobj = take ? obj : bobj; btri = take ? k : btri; bleaf = take ? tr.leaf_first : bleaf;
+                                brank = take ? tr.rank : brank; bprim = take ? -1 : bprim; bref = take ? false : bref;
+                                limf = take ? f32_up(bt - (double)w.t_enter) : limf;
                             }
                         }
-                        m_occ |= __ballot(leaf_occ);
+                        m_occ |= m_leaf_occ;
                         m_live &= ~(m_occ & m_shadow_lanes);  // any occluder settles a shadow query
                     }
                     if (next == FNODE_NONE) {
