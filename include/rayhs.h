@@ -28,6 +28,12 @@
 extern "C" {
 #endif
 
+/* ABI history.  Version 2 GREW rayhs_stats by 8 bytes (shadow_skipped behind kernel_ms) and added the rayhs_multi_*
+ * entry points.  The library writes sizeof(rayhs_stats) bytes of ITS version through every `stats` pointer, so a
+ * caller compiled against version 1 that asks for stats must be rebuilt against this header; it cannot be served
+ * by a version-2 library (callers that pass stats = NULL are unaffected).  A host that mirrors the structs by hand
+ * (a Haskell Storable instance, ctypes) checks its layout with rayhs_sizeof() at start-up and the version with
+ * rayhs_abi_version(); rayhs_amd/lib.py refuses a library that answers differently. */
 #define RAYHS_ABI_VERSION 2
 
 typedef enum {
@@ -128,6 +134,10 @@ enum { RAYHS_OUT_F32 = 0, RAYHS_OUT_F64 = 1, RAYHS_OUT_I16 = 2 };
                                   with FMA last bits differ and exact-tie cases (a ray parallel to a plane) can flip */
 #define RAYHS_FLAG_EXHAUSTIVE 2u /* visit exactly the reference's node set (no ordering, no pruning, no any-hit exit) */
 #define RAYHS_FLAG_COUNT      4u /* instrumented run: fill the work counters of rayhs_stats */
+#define RAYHS_FLAG_POW5_SQMUL 8u /* fresnel's x ^ (5 :: Int) (src/Material.hs:26-29) as GHC.Real defines (^): ((x*x)*(x*x))*x.  The
+                                  default is the flat product x*x*x*x*x that GHC's RULES "^5/Int" produce under -O (the
+                                  reference builds with -O2, build.sh:1).  No GHC was available to confirm which one the
+                                  reference binary runs; they differ by an ulp or two of the Fresnel factor */
 
 /* Rendering (src/RayHs.hs:41-45) plus the tiling needed to shard a frame.
  * Rows row0 <= y < row1 are considered; of those this call renders the rows
@@ -166,6 +176,9 @@ typedef struct rayhs_scene rayhs_scene;
 
 const char *rayhs_last_error(void);
 int rayhs_abi_version(void);
+/* sizeof, as this library was compiled, of the structs that cross the boundary by pointer; 0 for an unknown id */
+enum { RAYHS_SIZEOF_SCENE_DESC = 0, RAYHS_SIZEOF_CAMERA = 1, RAYHS_SIZEOF_RENDER_PARAMS = 2, RAYHS_SIZEOF_STATS = 3 };
+uint32_t rayhs_sizeof(int which);
 /* number of visible HIP devices (0 if none or the runtime is unusable) */
 int rayhs_device_count(void);
 

@@ -99,6 +99,7 @@ def lib():
         L.orc_r0.argtypes = [C.c_double, C.c_double]
         L.orc_fresnel.restype = C.c_double
         L.orc_fresnel.argtypes = [C.c_double, C.c_double]
+        L.orc_set_pow5_variant.argtypes = [C.c_int]
         L.orc_mod_floor.restype = C.c_double
         L.orc_mod_floor.argtypes = [C.c_double, C.c_double]
         L.orc_refract.argtypes = [d3, d3, C.c_double, C.c_double, d3]
@@ -271,6 +272,20 @@ class Scene:
                             out.ctypes.data, C.byref(st), nthreads) != 0:
             raise RuntimeError(lib().orc_last_error().decode())
         return out, st.as_dict()
+
+
+class pow5_variant:
+    """with pow5_variant(True): ... renders with fresnel's x ^ (5 :: Int) as square-and-multiply (GHC.Real's (^) un-rewritten)
+    instead of the default flat product (GHC -O RULES "^5/Int"); the kernels' RAYHS_FLAG_POW5_SQMUL is the same switch."""
+
+    def __init__(self, square_and_multiply):
+        self.flag = 1 if square_and_multiply else 0
+
+    def __enter__(self):
+        lib().orc_set_pow5_variant(self.flag)
+
+    def __exit__(self, *exc):
+        lib().orc_set_pow5_variant(0)
 
 
 def load_render_desc(path):

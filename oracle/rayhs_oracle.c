@@ -354,7 +354,14 @@ static double sq(double x) { return x * x; }              /* GHC (^) with expone
  * left-associated product u*u*u*u*u; only an un-optimised build runs the square-and-multiply definition
  * ((x*x)*(x*x))*x.  The two differ by at most an ulp or two of the Fresnel factor.  [from memory of base's
  * GHC/Real.hs -- no GHC here to confirm; DESIGN.md section 2] */
-static double pow5(double x) { return x * x * x * x * x; }
+/* The other reading stays selectable (orc_set_pow5_variant(1), RAYHS_FLAG_POW5_SQMUL in the kernels) until one Fresnel
+ * value from a real GHC -O2 build settles it: tests/golden/pow5_variants.json holds arguments on which the two differ. */
+static int g_pow5_sqmul = 0;
+void orc_set_pow5_variant(int square_and_multiply) { g_pow5_sqmul = square_and_multiply != 0; }
+static double pow5(double x) {
+    if (g_pow5_sqmul) return ((x * x) * (x * x)) * x;   /* GHC.Real (^) as defined: square-and-multiply */
+    return x * x * x * x * x;                           /* RULES "^5/Int": the default */
+}
 double orc_r0(double n1, double n2) { return sq((n1 - n2) / (n1 + n2)); }  /* Material.hs:22-24 */
 double orc_fresnel(double ior, double cos0) {                              /* Material.hs:26-29 */
     double r = orc_r0(1.0, ior);

@@ -122,6 +122,8 @@ void orc_trace_ray(const orc_scene *s, const double origin[3], const double dir[
                    int max_depth, double rgb[3]);
 double orc_r0(double n1, double n2);
 double orc_fresnel(double ior, double cos0);
+/* 0 (default): x^5 = x*x*x*x*x (GHC -O RULES "^5/Int"); 1: ((x*x)*(x*x))*x (GHC.Real's (^) un-rewritten).  Process-wide. */
+void orc_set_pow5_variant(int square_and_multiply);
 double orc_mod_floor(double n, double d);
 int orc_refract(const double i[3], const double n[3], double n1, double n2, double out[3]);
 void orc_color_at(const orc_material *m, double u, double v, double rgb[3]);

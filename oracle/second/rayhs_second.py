@@ -50,10 +50,15 @@ def pow2(u):                           # x ^ (2 :: Int)
     return u * u
 
 
+POW5_SQUARE_AND_MULTIPLY = False      # the other reading of x ^ (5 :: Int), kept selectable
+
+
 def pow5(u):
     """x ^ (5 :: Int) under GHC -O (build.sh:1 uses -O2): GHC.Real's RULES "^5/Int" rewrite a literal Int
     exponent 5 to the flat product u*u*u*u*u (left-associated); see DESIGN.md section 2 for why this and not the
     square-and-multiply of the un-optimised definition."""
+    if POW5_SQUARE_AND_MULTIPLY:
+        return ((u * u) * (u * u)) * u
     return u * u * u * u * u
 
 

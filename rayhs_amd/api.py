@@ -178,6 +178,18 @@ class MultiRendering:
         L.check(L.load().rayhs_multi_render(self._h, C.byref(self.desc.camera), C.byref(p), out.ctypes.data, C.byref(st)))
         return out, st.as_dict()
 
+    def ray_trace_into(self, d_out, spp=1, seed=24, row0=0, row1=None, stripe_rows=8, out_format=L.OUT_F64, flags=0):
+        """Same frame into a caller-owned DEVICE buffer on devices[0] (rayhs_multi_render_device); returns the stats."""
+        p = L.RenderParams()
+        p.width, p.height, p.max_depth = self.width, self.height, self.max_depth
+        p.spp, p.seed, p.row0 = spp, seed, row0
+        p.row1 = self.height if row1 is None else row1
+        p.stripe_rows, p.stripe_rank, p.stripe_count = stripe_rows, 0, 1
+        p.out_format, p.flags = out_format, flags
+        st = L.Stats()
+        L.check(L.load().rayhs_multi_render_device(self._h, C.byref(self.desc.camera), C.byref(p), C.c_void_p(d_out), C.byref(st)))
+        return st.as_dict()
+
     def shares(self):
         n = len(self.devices)
         sh, rows = (C.c_double * n)(), (C.c_int * n)()

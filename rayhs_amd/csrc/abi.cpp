@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rayhs.h"
@@ -93,6 +94,15 @@ struct rayhs_scene {
 
 extern "C" const char *rayhs_last_error(void) { return g_error.c_str(); }
 extern "C" int rayhs_abi_version(void) { return RAYHS_ABI_VERSION; }
+extern "C" uint32_t rayhs_sizeof(int which) {
+    switch (which) {
+    case RAYHS_SIZEOF_SCENE_DESC: return (uint32_t)sizeof(rayhs_scene_desc);
+    case RAYHS_SIZEOF_CAMERA: return (uint32_t)sizeof(rayhs_camera);
+    case RAYHS_SIZEOF_RENDER_PARAMS: return (uint32_t)sizeof(rayhs_render_params);
+    case RAYHS_SIZEOF_STATS: return (uint32_t)sizeof(rayhs_stats);
+    default: return 0;
+    }
+}
 extern "C" int rayhs_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -186,22 +196,32 @@ static int upload(rayhs_scene *s, const std::vector<T> &v, const T **out) {
 
 static double r0(double n1, double n2) { double q = (n1 - n2) / (n1 + n2); return q * q; }  // src/Material.hs:22-24
 
-extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayhs_scene **out) {
-    if (!out) return set_error(RAYHS_ERR_INVALID, "out is NULL");
-    *out = nullptr;
+// Everything rayhs_scene_create derives from a description before any device is touched: validation, the device
+// records of device_scene.h, triangle ranks, the fast BVH.  Packed ONCE; rayhs_multi_create uploads the same pack to
+// every device it lists (the host preparation used to be repeated per device, serially).
+struct PackedScene {
+    std::vector<DNode> nodes;
+    std::vector<DTri> tris, ftris;
+    std::vector<DTriAttr> attrs, fattrs;
+    std::vector<FNode> fnodes;
+    std::vector<DPlane> planes;
+    std::vector<DSphere> spheres;
+    std::vector<DMesh> meshes;
+    std::vector<DObject> objects;
+    std::vector<DLight> lights;
+    std::vector<double> texels;
+    int plane_axis_end[3] = {0, 0, 0};
+    int n_objects = 0, n_lights = 0, n_nodes = 0, n_tris = 0;
+    int tree_depth = -1, fast_depth = 0;
+};
+
+static int pack_scene(const rayhs_scene_desc *desc, PackedScene &pk) {
     int tree_depth = -1;
     int rc = check_desc(desc, tree_depth);
     if (rc) return rc;
-    int ndev = rayhs_device_count();
-    if (ndev <= 0) return set_error(RAYHS_ERR_NO_DEVICE, "no HIP device available (librayhs_hip has no CPU fallback)");
-    if (device < 0 || device >= ndev) return set_error(RAYHS_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
-    HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-
     // pack the SoA description into the device records of device_scene.h
     const rayhs_scene_desc &d = *desc;
-    std::vector<DNode> nodes((size_t)d.n_nodes);
+    std::vector<DNode> &nodes = pk.nodes; nodes.assign((size_t)d.n_nodes, DNode());
     for (int k = 0; k < d.n_nodes; k++) {
         DNode &n = nodes[(size_t)k];
         for (int c = 0; c < 3; c++) { n.lo[c] = d.node_lo[3 * k + c]; n.hi[c] = d.node_hi[3 * k + c]; }
@@ -225,17 +245,18 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
         for (int c = 0; c < 2; c++) { a.uv0[c] = uv[c]; a.uv1[c] = uv[2 + c]; a.uv2[c] = uv[4 + c]; }
         a.leaf_node = -1; a.pad = 0;
     };
-    std::vector<DTri> tris((size_t)d.n_tris);
-    std::vector<DTriAttr> attrs((size_t)d.n_tris);
+    std::vector<DTri> &tris = pk.tris; tris.assign((size_t)d.n_tris, DTri());
+    std::vector<DTriAttr> &attrs = pk.attrs; attrs.assign((size_t)d.n_tris, DTriAttr());
     for (int k = 0; k < d.n_tris; k++) {
         pack_tri(k, tris[(size_t)k], attrs[(size_t)k]);
         tris[(size_t)k].rank = k; tris[(size_t)k].leaf_first = k;  // overwritten for triangles reachable from a tree
     }
     // per mesh: the reference's left-to-right leaf order gives every triangle its rank (exact-t ties are
     // resolved by it), then the fast BVH is built over the same triangles and they are re-ordered into its leaves
-    std::vector<FNode> fnodes;
-    std::vector<DTri> ftris;
-    std::vector<DTriAttr> fattrs;
+    std::vector<FNode> &fnodes = pk.fnodes;
+    std::vector<DTri> &ftris = pk.ftris;
+    std::vector<DTriAttr> &fattrs = pk.fattrs;
+    fnodes.clear(); ftris.clear(); fattrs.clear();
     std::vector<int> mesh_froot((size_t)d.n_meshes, FNODE_NONE), mesh_tri_base((size_t)d.n_meshes, 0);
     std::vector<double> mesh_center(3 * (size_t)d.n_meshes, 0.0);
     std::vector<float> mesh_fbox(6 * (size_t)d.n_meshes, 0.0f);
@@ -302,10 +323,10 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
             fattrs.push_back(attrs[(size_t)t]);
         }
     }
-    std::vector<DPlane> planes((size_t)d.n_planes);
-    std::vector<DSphere> spheres((size_t)d.n_spheres);
-    std::vector<DMesh> meshes((size_t)d.n_meshes);
-    std::vector<DObject> objects((size_t)d.n_objects);
+    std::vector<DPlane> &planes = pk.planes; planes.assign((size_t)d.n_planes, DPlane());
+    std::vector<DSphere> &spheres = pk.spheres; spheres.assign((size_t)d.n_spheres, DSphere());
+    std::vector<DMesh> &meshes = pk.meshes; meshes.assign((size_t)d.n_meshes, DMesh());
+    std::vector<DObject> &objects = pk.objects; objects.assign((size_t)d.n_objects, DObject());
     std::vector<char> plane_used((size_t)d.n_planes, 0), sphere_used((size_t)d.n_spheres, 0), mesh_used((size_t)d.n_meshes, 0);
     for (int i = 0; i < d.n_objects; i++) {
         DObject &o = objects[(size_t)i];
@@ -364,7 +385,8 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
     // Planes grouped by the single non-zero component of their normal (x, y, z), general position last: for a finite ray
     // the two dot products of the plane test then consist of ONE product plus two exact zeros (trace_kernel.hip,
     // plane loop).  Closest-hit ties are decided by the object index, never by the storage order.
-    int plane_axis_end[3] = {0, 0, 0};
+    int (&plane_axis_end)[3] = pk.plane_axis_end;
+    plane_axis_end[0] = plane_axis_end[1] = plane_axis_end[2] = 0;
     {
         auto axis_of = [](const DPlane &p) {
             for (int c = 0; c < 3; c++)
@@ -384,43 +406,58 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
         }
         planes.swap(grouped);
     }
-    std::vector<DLight> lights((size_t)d.n_lights);
+    std::vector<DLight> &lights = pk.lights; lights.assign((size_t)d.n_lights, DLight());
     for (int i = 0; i < d.n_lights; i++) {
         DLight &l = lights[(size_t)i];
         l.kind = d.light_kind[i]; l.pad = 0;
         for (int c = 0; c < 3; c++) { l.v[c] = d.light_vec[3 * i + c]; l.c[c] = d.light_color[3 * i + c]; }
         l.radius = d.light_radius[i];
     }
-    std::vector<double> texels;
-    if (d.n_texels > 0) texels.assign(d.texels, d.texels + 3 * (size_t)d.n_texels);
+    pk.texels.clear();
+    if (d.n_texels > 0) pk.texels.assign(d.texels, d.texels + 3 * (size_t)d.n_texels);
 
+    pk.n_objects = d.n_objects; pk.n_lights = d.n_lights; pk.n_nodes = d.n_nodes; pk.n_tris = d.n_tris;
+    pk.tree_depth = tree_depth; pk.fast_depth = fast_depth;
+    return RAYHS_OK;
+}
+
+// one device's copy of a packed scene (HBM-resident until destroy) plus its launch state
+static int upload_scene(const PackedScene &pk, int device, rayhs_scene **out) {
+    *out = nullptr;
+    int ndev = rayhs_device_count();
+    if (ndev <= 0) return set_error(RAYHS_ERR_NO_DEVICE, "no HIP device available (librayhs_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return set_error(RAYHS_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    int rc;
     rayhs_scene *s = new rayhs_scene();
     s->device = device;
     s->cu_count = prop.multiProcessorCount;
-    s->tree_depth = tree_depth;
-    s->fast_depth = fast_depth;
+    s->tree_depth = pk.tree_depth;
+    s->fast_depth = pk.fast_depth;
     auto fail = [&](int code) { rayhs_scene_destroy(s); return code; };
-    if ((rc = upload(s, nodes, &s->d.nodes))) return fail(rc);
-    if ((rc = upload(s, tris, &s->d.tris))) return fail(rc);
-    if ((rc = upload(s, attrs, &s->d.attrs))) return fail(rc);
-    if ((rc = upload(s, fnodes, &s->d.fnodes))) return fail(rc);
-    if ((rc = upload(s, ftris, &s->d.ftris))) return fail(rc);
-    if ((rc = upload(s, fattrs, &s->d.fattrs))) return fail(rc);
-    if ((rc = upload(s, planes, &s->d.planes))) return fail(rc);
-    if ((rc = upload(s, spheres, &s->d.spheres))) return fail(rc);
-    if ((rc = upload(s, meshes, &s->d.meshes))) return fail(rc);
-    if ((rc = upload(s, objects, &s->d.objects))) return fail(rc);
-    if ((rc = upload(s, lights, &s->d.lights))) return fail(rc);
-    if ((rc = upload(s, texels, &s->d.texels))) return fail(rc);
-    s->d.n_planes = (int)planes.size();
-    for (int a = 0; a < 3; a++) s->d.plane_axis_end[a] = plane_axis_end[a];
-    s->d.n_spheres = (int)spheres.size();
-    s->d.n_meshes = (int)meshes.size();
-    s->d.n_objects = d.n_objects;
-    s->d.n_lights = d.n_lights;
-    s->d.n_nodes = d.n_nodes;
-    s->d.n_tris = d.n_tris;
-    s->d.n_fnodes = (int)fnodes.size();
+    if ((rc = upload(s, pk.nodes, &s->d.nodes))) return fail(rc);
+    if ((rc = upload(s, pk.tris, &s->d.tris))) return fail(rc);
+    if ((rc = upload(s, pk.attrs, &s->d.attrs))) return fail(rc);
+    if ((rc = upload(s, pk.fnodes, &s->d.fnodes))) return fail(rc);
+    if ((rc = upload(s, pk.ftris, &s->d.ftris))) return fail(rc);
+    if ((rc = upload(s, pk.fattrs, &s->d.fattrs))) return fail(rc);
+    if ((rc = upload(s, pk.planes, &s->d.planes))) return fail(rc);
+    if ((rc = upload(s, pk.spheres, &s->d.spheres))) return fail(rc);
+    if ((rc = upload(s, pk.meshes, &s->d.meshes))) return fail(rc);
+    if ((rc = upload(s, pk.objects, &s->d.objects))) return fail(rc);
+    if ((rc = upload(s, pk.lights, &s->d.lights))) return fail(rc);
+    if ((rc = upload(s, pk.texels, &s->d.texels))) return fail(rc);
+    s->d.n_planes = (int)pk.planes.size();
+    for (int a = 0; a < 3; a++) s->d.plane_axis_end[a] = pk.plane_axis_end[a];
+    s->d.n_spheres = (int)pk.spheres.size();
+    s->d.n_meshes = (int)pk.meshes.size();
+    s->d.n_objects = pk.n_objects;
+    s->d.n_lights = pk.n_lights;
+    s->d.n_nodes = pk.n_nodes;
+    s->d.n_tris = pk.n_tris;
+    s->d.n_fnodes = (int)pk.fnodes.size();
     void *p = nullptr;
     if (hipMalloc(&p, sizeof(unsigned long long) * kTicketSlots * kTicketRings) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(tickets) failed"));
     s->tickets = (unsigned long long *)p;
@@ -428,6 +465,16 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
     s->counters = (unsigned long long *)p;
     *out = s;
     return RAYHS_OK;
+}
+
+extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayhs_scene **out) {
+    if (!out) return set_error(RAYHS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    // (validation and packing come first: a bad description is reported as such even where no device exists)
+    PackedScene pk;
+    int rc = pack_scene(desc, pk);
+    if (rc) return rc;
+    return upload_scene(pk, device, out);
 }
 
 extern "C" void rayhs_scene_destroy(rayhs_scene *s) {
@@ -508,6 +555,7 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     dp.stripe_rows = p->stripe_rows; dp.stripe_rank = p->stripe_rank; dp.stripe_count = p->stripe_count;
     if (sl) { dp.stripe_map = sl->d_map; dp.stripe_rank = sl->id; dp.stripe_count = 0; }  // rank / count are unused with a list (the rank slot keys the tile-order cache)
     dp.out_format = p->out_format;
+    dp.flags_dev = (p->flags & RAYHS_FLAG_POW5_SQMUL) ? 2 : 0;
     // samples of a pixel are folded inside the wave when they all sit in one 64-item chunk (trace_kernel.hip)
     dp.wave_resolve = (p->spp > 1 && 64 % p->spp == 0 && !std::getenv("RAYHS_NO_WAVE_RESOLVE")) ? 1 : 0;
     auto log2_exact = [](int v) { int s = 0; while ((1 << s) < v) s++; return (1 << s) == v ? s : -1; };
@@ -815,26 +863,49 @@ extern "C" int rayhs_multi_create(const rayhs_scene_desc *desc, const int *devic
     m->out_dev.assign(n, nullptr); m->out_bytes.assign(n, 0); m->map_dev.assign(n, nullptr); m->map_cap.assign(n, 0); m->counters.assign(n, nullptr);
     m->lists.assign(n, StripeList()); m->est_share.assign(n, 0.0); m->kernel_ms.assign(n, 0.0);
     auto fail = [&](int code) { rayhs_multi_destroy(m); return code; };
-    for (size_t i = 0; i < n; i++) {
-        // the same device may be listed more than once (a one-GPU rehearsal of the N-GPU path): every entry gets its own
-        // scene copy, stream and buffers, exactly as N different GPUs would
-        int rc = rayhs_scene_create(desc, devices[i], &m->scenes[i]);
+    // host preparation (validation, records, triangle ranks, SAH BVH) once for all entries ...
+    PackedScene pk;
+    {
+        int rc = pack_scene(desc, pk);
         if (rc) return fail(rc);
-        if (hipStreamCreateWithFlags(&m->streams[i], hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->e0[i]) != hipSuccess ||
-            hipEventCreate(&m->e1[i]) != hipSuccess || hipEventCreateWithFlags(&m->done[i], hipEventDisableTiming) != hipSuccess)
-            return fail(set_error(RAYHS_ERR_HIP, "stream / event creation failed on device %d", devices[i]));
+    }
+    // ... then one upload per entry, the entries side by side (one host thread each: the copies of different devices do
+    // not wait for each other).  The same device may be listed more than once (a one-GPU rehearsal of the N-GPU path):
+    // every entry gets its own scene copy, stream and buffers, exactly as N different GPUs would.
+    std::vector<int> codes(n, RAYHS_OK);
+    std::vector<std::string> messages(n);
+    auto bring_up = [&](size_t i) {
+        int rc = upload_scene(pk, devices[i], &m->scenes[i]);
+        if (rc == RAYHS_OK &&
+            (hipStreamCreateWithFlags(&m->streams[i], hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->e0[i]) != hipSuccess ||
+             hipEventCreate(&m->e1[i]) != hipSuccess || hipEventCreateWithFlags(&m->done[i], hipEventDisableTiming) != hipSuccess))
+            rc = set_error(RAYHS_ERR_HIP, "stream / event creation failed on device %d", devices[i]);
         void *p = nullptr;
-        if (hipMalloc(&p, sizeof(unsigned long long) * CNT_SLOTS_DEV) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(counters) failed"));
-        m->counters[i] = (unsigned long long *)p;
-        if (devices[i] != devices[0]) {  // this device will write its stripes into the frame on devices[0]
+        if (rc == RAYHS_OK && hipMalloc(&p, sizeof(unsigned long long) * CNT_SLOTS_DEV) != hipSuccess) rc = set_error(RAYHS_ERR_HIP, "hipMalloc(counters) failed");
+        if (rc == RAYHS_OK) m->counters[i] = (unsigned long long *)p;
+        if (rc == RAYHS_OK && devices[i] != devices[0]) {  // this device will write its stripes into the frame on devices[0]
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) != hipSuccess || !can)
-                return fail(set_error(RAYHS_ERR_UNSUPPORTED, "device %d has no peer access to device %d", devices[i], devices[0]));
-            hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(set_error(RAYHS_ERR_HIP, "hipDeviceEnablePeerAccess failed: %s", hipGetErrorString(e)));
-            (void)hipGetLastError();
+                rc = set_error(RAYHS_ERR_UNSUPPORTED, "device %d has no peer access to device %d", devices[i], devices[0]);
+            else {
+                hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = set_error(RAYHS_ERR_HIP, "hipDeviceEnablePeerAccess failed: %s", hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
         }
+        codes[i] = rc;
+        if (rc) messages[i] = g_error;  // (the error text is thread-local: carried back to the calling thread below)
+    };
+    if (n == 1 || std::getenv("RAYHS_MULTI_SERIAL_CREATE")) {
+        for (size_t i = 0; i < n; i++) bring_up(i);
+    } else {
+        std::vector<std::thread> workers;
+        for (size_t i = 0; i < n; i++) workers.emplace_back(bring_up, i);
+        for (auto &w : workers) w.join();
     }
+    for (size_t i = 0; i < n; i++)
+        if (codes[i]) { g_error = messages[i]; return fail(codes[i]); }
+    (void)hipSetDevice(devices[0]);
     *out = m;
     return RAYHS_OK;
 }
@@ -979,7 +1050,10 @@ static int multi_render(rayhs_multi *m, const rayhs_camera *cam, const rayhs_ren
         frame = m->frame;
     }
     const bool count = (p.flags & RAYHS_FLAG_COUNT) != 0, exact = (p.flags & RAYHS_FLAG_FMA) == 0;
-    for (size_t i = 0; i < n; i++) {
+    // One device's share: trace its stripes, push them into the frame on devices[0].  (A lambda so that a failure on
+    // device i can be handled in ONE place below: the devices launched before it are still tracing and scattering
+    // into the caller's frame, and the call must not return while they do.)
+    auto launch_share = [&](size_t i) -> int {
         const StripeList &sl = m->lists[i];
         HIP_TRY(hipSetDevice(m->devices[i]));
         if (count) HIP_TRY(hipMemsetAsync(m->counters[i], 0, sizeof(unsigned long long) * CNT_SLOTS_DEV, m->streams[i]));
@@ -990,8 +1064,8 @@ static int multi_render(rayhs_multi *m, const rayhs_camera *cam, const rayhs_ren
             HIP_TRY(hipMalloc(&m->out_dev[i], std::max<size_t>(need, 16)));
             m->out_bytes[i] = std::max<size_t>(need, 16);
         }
-        rc = launch(m->scenes[i], cam, &p, m->out_dev[i], m->streams[i], count ? (uint64_t *)m->counters[i] : nullptr, m->e0[i], m->e1[i], &sl);
-        if (rc) return rc;
+        int rc_i = launch(m->scenes[i], cam, &p, m->out_dev[i], m->streams[i], count ? (uint64_t *)m->counters[i] : nullptr, m->e0[i], m->e1[i], &sl);
+        if (rc_i) return rc_i;
         // push the finished stripes to their rows of the frame on devices[0] (peer write over xGMI)
         hipError_t e = exact ? launch_scatter_stripes_exact(m->streams[i], m->out_dev[i], frame, sl.d_map, sl.rows, p.stripe_rows, (long long)row_bytes)
                              : launch_scatter_stripes_fast(m->streams[i], m->out_dev[i], frame, sl.d_map, sl.rows, p.stripe_rows, (long long)row_bytes);
@@ -999,6 +1073,18 @@ static int multi_render(rayhs_multi *m, const rayhs_camera *cam, const rayhs_ren
         HIP_TRY(hipEventRecord(m->done[i], m->streams[i]));
         // development (tools/stripe_balance.py): one share at a time, so that entries sharing a GPU are timed as if each had its own
         if (std::getenv("RAYHS_MULTI_SERIAL")) HIP_TRY(hipStreamSynchronize(m->streams[i]));
+        return RAYHS_OK;
+    };
+    for (size_t i = 0; i < n; i++) {
+        rc = launch_share(i);
+        if (rc) {
+            const std::string why = g_error;
+            for (size_t k = 0; k <= i; k++)  // the shares already under way finish before the caller gets its buffer back
+                if (hipSetDevice(m->devices[k]) == hipSuccess) (void)hipStreamSynchronize(m->streams[k]);
+            (void)hipSetDevice(m->devices[0]);
+            g_error = why;
+            return rc;
+        }
     }
     HIP_TRY(hipSetDevice(m->devices[0]));
     for (size_t i = 1; i < n; i++) HIP_TRY(hipStreamWaitEvent(m->streams[0], m->done[i], 0));

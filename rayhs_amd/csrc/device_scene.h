@@ -139,7 +139,7 @@ struct DParams {
     const int32_t *tile_order;        // work order of the 8x8 tiles, slowest first (NULL: scan order); from the previous frame's tile_cost
     const int32_t *stripe_map;        // NULL: round-robin stripes (stripe_rank / stripe_count); else the global stripe index of every
                                       // local stripe of this launch, ascending (rayhs_multi: cost-balanced ownership)
-    int32_t flags_dev, pad_dev;       // development switches of the helper kernels (bit 0: rayhs_static_costs emits its raw feature)
+    int32_t flags_dev, pad_dev;       // development switches of the helper kernels (bit 0: rayhs_static_costs emits its raw feature); bit 1: RAYHS_FLAG_POW5_SQMUL
     float *tile_cost;                 // per tile: longest time (100 MHz ticks) one of its chunks took in THIS frame (NULL: not recorded)
 };
 

@@ -175,9 +175,12 @@ template <class OB> DEV V3 color_at(const OB &o, const double *texels, double u,
 
 // fresnel (src/Material.hs:26-29); r = r0 1.0 ior precomputed.  (^ (5 :: Int)) is the flat product u*u*u*u*u that
 // GHC's rewrite RULES "^5/Int" (GHC.Real) produce with optimisation on (build.sh:1: -O2), not square-and-multiply
-DEV double fresnel(double r, double cos0) {
+// (RAYHS_FLAG_POW5_SQMUL selects the un-rewritten definition instead, wave-uniformly: DParams.flags_dev bit 1)
+DEV double fresnel(double r, double cos0, bool sqmul) {
     double x = 1 - cos0;
-    return r + (1 - r) * ((((x * x) * x) * x) * x);
+    const double x2 = x * x;
+    const double p5 = sqmul ? (x2 * x2) * x : ((x2 * x) * x) * x;
+    return r + (1 - r) * p5;
 }
 
 // splitmix64 finaliser: the build-defined counter sampler (include/rayhs.h, rayhs_sample01)
@@ -1173,7 +1176,7 @@ static __device__ __forceinline__ void trace_body() {
                         V3 c_v = LOAD_V();
                         V3 rf = reflect(c_v, c_n);
                         ws_store(ws, fslot(fsp, FS_KIND), (double)FR_TRANS_WAIT_RADIANCE);
-                        ws_store(ws, fslot(fsp, FS_F), fresnel(ob.fr, dot(c_n, neg(c_v))));
+                        ws_store(ws, fslot(fsp, FS_F), fresnel(ob.fr, dot(c_n, neg(c_v)), (PRM.flags_dev & 2) != 0));
                         ws_store(ws, fslot(fsp, FS_S), dot(rf, c_n));
                         ws_store(ws, fslot(fsp, FS_K), ob.one_m_r0);
                         ws_store3(ws, fslot(fsp, FS_RO), add(c_p, scl(kEps, rf)));
@@ -1238,7 +1241,7 @@ static __device__ __forceinline__ void trace_body() {
                 const auto &ob = rec(SC.objects, c_obj);
                 const V3 c_n = cx_load3(cx, CX_N);
                 V3 c_v = LOAD_V();
-                double F = fresnel(ob.fr, dot(c_n, neg(c_v)));
+                double F = fresnel(ob.fr, dot(c_n, neg(c_v)), (PRM.flags_dev & 2) != 0);
                 if (fsp < PRM.max_depth) {
                     V3 rf = reflect(c_v, c_n);
                     ws_store(ws, fslot(fsp, FS_KIND), (double)(spec_with_A ? FR_PLASTIC : FR_MIRROR));

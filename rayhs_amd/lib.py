@@ -16,7 +16,7 @@ CLI_PATH = os.path.join(_HERE, "bin", "rayhs")
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 GEOM_PLANE, GEOM_SPHERE, GEOM_MESH = 0, 1, 2
 OUT_F32, OUT_F64, OUT_I16 = 0, 1, 2
-FLAG_FMA, FLAG_EXHAUSTIVE, FLAG_COUNT = 1, 2, 4
+FLAG_FMA, FLAG_EXHAUSTIVE, FLAG_COUNT, FLAG_POW5_SQMUL = 1, 2, 4, 8
 
 _pi32 = C.POINTER(C.c_int32)
 _pi64 = C.POINTER(C.c_int64)
@@ -73,6 +73,7 @@ class Stats(C.Structure):
 SYMBOLS = [
     ("rayhs_last_error", C.c_char_p, []),
     ("rayhs_abi_version", C.c_int, []),
+    ("rayhs_sizeof", C.c_uint32, [C.c_int]),
     ("rayhs_device_count", C.c_int, []),
     ("rayhs_scene_create", C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
     ("rayhs_scene_destroy", None, [C.c_void_p]),
@@ -101,6 +102,7 @@ SYMBOLS = [
     ("rayhs_sample01", C.c_double, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
 ]
 
+ABI_VERSION = 2   # RAYHS_ABI_VERSION this binding was written against
 _LIB = None
 
 
@@ -123,6 +125,14 @@ def load():
             f = getattr(lib, name)
             f.restype = res
             f.argtypes = args
+        # the structs below are hand-written mirrors: refuse a library of another ABI version or another layout
+        # instead of letting it write past them (version 2 grew rayhs_stats; include/rayhs.h, "ABI history")
+        if lib.rayhs_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} implements ABI version {lib.rayhs_abi_version()}, this binding needs {ABI_VERSION}: rebuild it")
+        for which, (name, cls) in enumerate((("rayhs_scene_desc", SceneDesc), ("rayhs_camera", Camera),
+                                             ("rayhs_render_params", RenderParams), ("rayhs_stats", Stats))):
+            if lib.rayhs_sizeof(which) != C.sizeof(cls):
+                raise ImportError(f"{LIB_PATH}: sizeof({name}) is {lib.rayhs_sizeof(which)} in the library, {C.sizeof(cls)} in rayhs_amd/lib.py")
         _LIB = lib
     return _LIB
 

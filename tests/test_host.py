@@ -53,6 +53,29 @@ def test_struct_sizes_match_the_header():
     assert C.sizeof(L.RenderParams) == 56
     assert C.sizeof(L.Stats) == 12 * 8
     assert C.sizeof(L.SceneDesc) == 328
+    # ... and against the library itself (rayhs_sizeof): a library of another layout must never be written into
+    for which, cls in enumerate((L.SceneDesc, L.Camera, L.RenderParams, L.Stats)):
+        assert L.load().rayhs_sizeof(which) == C.sizeof(cls)
+    assert L.load().rayhs_sizeof(99) == 0
+
+
+def test_loader_refuses_a_library_of_another_abi_version_or_layout(monkeypatch):
+    # ABI version 2 grew rayhs_stats by 8 bytes; a caller that mirrors version 1 would be overrun by 8 bytes when it
+    # asks for stats (include/rayhs.h, "ABI history").  The binding checks version and struct sizes when it loads.
+    monkeypatch.setattr(L, "_LIB", None)
+    monkeypatch.setattr(L, "ABI_VERSION", 1)
+    with pytest.raises(ImportError, match="ABI version 2"):
+        L.load()
+    monkeypatch.setattr(L, "ABI_VERSION", 2)
+
+    class Stats88(C.Structure):  # the version-1 layout: no shadow_skipped
+        _fields_ = L.Stats._fields_[:-1]
+    assert C.sizeof(Stats88) == 88
+    monkeypatch.setattr(L, "Stats", Stats88)
+    with pytest.raises(ImportError, match=r"sizeof\(rayhs_stats\) is 96"):
+        L.load()
+    monkeypatch.undo()
+    assert L.load().rayhs_abi_version() == 2
 
 
 def test_sampler_matches_oracle_definition():

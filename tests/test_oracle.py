@@ -49,6 +49,31 @@ def test_fresnel_schlick_and_power_chain():
     assert L.orc_fresnel(1.9, -0.5) > 1.0                    # cos0 < 0 exceeds 1
 
 
+def test_both_readings_of_the_fifth_power_against_hand_computed_vectors():
+    # tests/golden/pow5_variants.json (plain float arithmetic, make_pow5_variants.py): arguments on which the flat product
+    # x*x*x*x*x (GHC -O RULES "^5/Int", the default) and square-and-multiply ((x*x)*(x*x))*x (GHC.Real's (^)) differ.
+    # Both restatements switch together, so that one value from a real GHC -O2 build can settle the reading later
+    # without touching the kernels' sources (RAYHS_FLAG_POW5_SQMUL is the same switch on the GPU).
+    import json
+    from oracle.second import rayhs_second as S2
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pow5_variants.json")))
+    assert gold["default"] == "flat" and len(gold["vectors"]) >= 16
+    L = O.lib()
+    for v in gold["vectors"]:
+        ior, c = float.fromhex(v["ior"]), float.fromhex(v["cos0"])
+        flat, sqmul = float.fromhex(v["flat"]), float.fromhex(v["sqmul"])
+        assert flat != sqmul
+        assert L.orc_fresnel(ior, c) == flat and S2.fresnel(ior, c) == flat
+        with O.pow5_variant(True):
+            assert L.orc_fresnel(ior, c) == sqmul
+        S2.POW5_SQUARE_AND_MULTIPLY = True
+        try:
+            assert S2.fresnel(ior, c) == sqmul
+        finally:
+            S2.POW5_SQUARE_AND_MULTIPLY = False
+        assert L.orc_fresnel(ior, c) == flat          # the switch is back at the default
+
+
 # ---- Vec.hs:128-140
 def test_refract_straight_through_and_total_internal_reflection():
     L = O.lib()
