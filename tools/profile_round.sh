@@ -22,5 +22,7 @@ pmc fetch FETCH_SIZE || exit 3
 pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum || exit 4
 pmc sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU || exit 5
 pmc sq2 SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_FLAT GRBM_GUI_ACTIVE || exit 6
+# instruction mix: what the vector pipe is really asked for (fp64 arithmetic runs at half rate, transcendentals at an eighth) and the branches
+pmc mix SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES || exit 7
 RAYHS_DEBUG_COUNTERS=1 python3 tools/kbench.py $wl 1 2>&1 | grep "rayhs launch" | tail -1 > ${pre}_launch.txt
 cat ${pre}_bench.json

@@ -68,6 +68,20 @@ for k, d in out["pmc_mean_per_launch"].items():
                 d[c + "_per_wave_cycle"] = d[c] / d["SQ_WAVE_CYCLES"]
     if "SQ_INSTS_SALU" in d and "SQ_INSTS_VALU" in d:
         d["salu_per_valu"] = d["SQ_INSTS_SALU"] / d["SQ_INSTS_VALU"]
+    # Cycles the vector PIPE needs for the instructions issued (MI355X_MICROARCH.md: a SIMD is 32 lanes wide, so a
+    # wave64 fp32 / integer instruction occupies it for 2 cycles, fp64 add / mul / fma for 4 (half rate), fp64 rcp / sqrt
+    # for 16), against the SIMD-cycles of the launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs).  SQ_ACTIVE_INST_VALU --
+    # `valu_busy` -- counts 4 cycles per instruction whatever its kind: it is ISSUE time of the waves, not pipe occupancy.
+    f64 = [d.get("SQ_INSTS_VALU_" + k) for k in ("ADD_F64", "MUL_F64", "FMA_F64")]
+    if all(v is not None for v in f64) and "SQ_INSTS_VALU_TRANS_F64" in d and "GRBM_GUI_ACTIVE" in d:
+        arith, trans = sum(f64), d["SQ_INSTS_VALU_TRANS_F64"]
+        pipe_cycles = 4 * arith + 16 * trans + 2 * (d["SQ_INSTS_VALU"] - arith - trans)
+        simd_cycles = d["GRBM_GUI_ACTIVE"] / 8 * 256 * 4
+        d["valu_f64_share_of_insts"] = (arith + trans) / d["SQ_INSTS_VALU"]
+        d["valu_pipe_frac"] = pipe_cycles / simd_cycles
+        d["fp64_flops_per_launch"] = 64.0 * (f64[0] + f64[1] + 2 * f64[2])   # wave-level instructions x 64 lanes (an upper bound: idle lanes count)
+    if "SQ_INSTS_BRANCH" in d and "SQ_INSTS_VALU" in d:
+        d["branches_per_valu"] = d["SQ_INSTS_BRANCH"] / d["SQ_INSTS_VALU"]
 # dispatch: the code object's own metadata + the launch the library reports
 disp = {}
 try:
