@@ -23,12 +23,12 @@ hipError_t launch_trace_fast(int variant, int grid, size_t lds_bytes, hipStream_
                              const DParams &prm, void *out, unsigned long long *counters, unsigned long long *ticket, double *frames);
 hipError_t launch_resolve_fast(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format);
 hipError_t launch_resolve_exact(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format);
-hipError_t launch_order_tiles_fast(hipStream_t stream, float *cost, int n, int *order);
+hipError_t launch_order_tiles_fast(hipStream_t stream, float *cost, int n, int *order, unsigned *aux, unsigned long long *next_ticket, int ticket_slots);
 hipError_t launch_scatter_stripes_fast(hipStream_t stream, const void *src, void *dst, const int *stripe_map, int n_rows, int stripe_rows, long long row_bytes);
 hipError_t launch_scatter_stripes_exact(hipStream_t stream, const void *src, void *dst, const int *stripe_map, int n_rows, int stripe_rows, long long row_bytes);
 hipError_t launch_static_costs_fast(hipStream_t stream, const DScene &sc, const DCamera &cam, const DParams &prm, float *cost);
 hipError_t launch_static_costs_exact(hipStream_t stream, const DScene &sc, const DCamera &cam, const DParams &prm, float *cost);
-hipError_t launch_order_tiles_exact(hipStream_t stream, float *cost, int n, int *order);
+hipError_t launch_order_tiles_exact(hipStream_t stream, float *cost, int n, int *order, unsigned *aux, unsigned long long *next_ticket, int ticket_slots);
 hipError_t launch_trace_exact(int variant, int grid, size_t lds_bytes, hipStream_t stream, const DScene &sc, const DCamera &cam,
                               const DParams &prm, void *out, unsigned long long *counters, unsigned long long *ticket, double *frames);
 int occupancy_trace_fast(int variant, size_t lds_bytes);
@@ -77,6 +77,8 @@ struct rayhs_scene {
     // feedback scheduling (plan_tile_order): chunk times measured by a frame order the tiles of the next one
     mutable int32_t *order_dev = nullptr;
     mutable float *cost_dev = nullptr;
+    mutable unsigned *order_aux = nullptr;       // the ordering kernels' histogram rows (ORDER_MAX_BLOCKS x 1024)
+    mutable long long ticket_clean_for = -1;     // launch number whose ticket counters the previous launch's ordering kernel has already zeroed
     mutable size_t order_cap = 0;
     mutable bool order_valid = false;            // order_dev holds an order for order_key
     mutable int order_key[10] = {0};             // frame geometry the order and the costs belong to
@@ -484,6 +486,7 @@ extern "C" void rayhs_scene_destroy(rayhs_scene *s) {
     if (s->frames) (void)hipFree(s->frames);
     if (s->order_dev) (void)hipFree(s->order_dev);
     if (s->cost_dev) (void)hipFree(s->cost_dev);
+    if (s->order_aux) (void)hipFree(s->order_aux);
     if (s->sbuf) (void)hipFree(s->sbuf);
     if (s->tickets) (void)hipFree(s->tickets);
     if (s->counters) (void)hipFree(s->counters);
@@ -660,6 +663,11 @@ static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, i
             s->cost_dev = (float *)q;
             s->order_cap = (size_t)dp.n_tiles;
         }
+        if (!s->order_aux) {
+            void *q = nullptr;
+            HIP_TRY(hipMalloc(&q, (size_t)ORDER_MAX_BLOCKS * 1024 * sizeof(unsigned)));  // (written whole by every ordering: never cleared)
+            s->order_aux = (unsigned *)q;
+        }
         HIP_TRY(hipMemsetAsync(s->cost_dev, 0, (size_t)dp.n_tiles * sizeof(float), st));  // once per geometry, in stream order; afterwards the ordering kernel clears it
         std::memcpy(s->order_key, key, sizeof key);
     }
@@ -691,12 +699,16 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
     if ((rc = ensure_workspace(s, dp, st))) return rc;
     bool record_costs = false, static_order = false;
     if ((rc = plan_tile_order(s, p, variant, dp, st, record_costs, static_order))) return rc;
-    unsigned long long *ticket = s->tickets + (size_t)(s->next_ticket++ % kTicketRings) * kTicketSlots;
-    HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long) * kTicketSlots, st));
+    // ticket counters of this launch: zeroed here, unless the ordering kernel behind the previous launch of this handle has
+    // already done it (one fill kernel and one launch gap less per frame in a steady-state loop)
+    const unsigned launch_no = s->next_ticket++;
+    unsigned long long *ticket = s->tickets + (size_t)(launch_no % kTicketRings) * kTicketSlots;
+    unsigned long long *next_ticket = s->tickets + (size_t)((launch_no + 1) % kTicketRings) * kTicketSlots;
+    if (s->ticket_clean_for != (long long)launch_no) HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long) * kTicketSlots, st));
     dp.sbuf = dp.spp > 1 && !dp.wave_resolve ? s->sbuf : nullptr;
     if (static_order) {  // first frame of this geometry: static tile classes -> work order (two tiny kernels, ~20 us)
         hipError_t es = exact ? launch_static_costs_exact(st, s->d, dc, dp, s->cost_dev) : launch_static_costs_fast(st, s->d, dc, dp, s->cost_dev);
-        if (es == hipSuccess) es = exact ? launch_order_tiles_exact(st, s->cost_dev, dp.n_tiles, s->order_dev) : launch_order_tiles_fast(st, s->cost_dev, dp.n_tiles, s->order_dev);
+        if (es == hipSuccess) es = exact ? launch_order_tiles_exact(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, nullptr, 0) : launch_order_tiles_fast(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, nullptr, 0);
         if (es != hipSuccess) return set_error(RAYHS_ERR_HIP, "static tile ordering launch failed: %s", hipGetErrorString(es));
     }
     if (e0) HIP_TRY(hipEventRecord(e0, st));
@@ -726,9 +738,10 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
         }
     }
     if (record_costs) {  // this frame's chunk times -> the next frame's tile order
-        e = exact ? launch_order_tiles_exact(st, s->cost_dev, dp.n_tiles, s->order_dev) : launch_order_tiles_fast(st, s->cost_dev, dp.n_tiles, s->order_dev);
+        e = exact ? launch_order_tiles_exact(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, next_ticket, kTicketSlots) : launch_order_tiles_fast(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, next_ticket, kTicketSlots);
         if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "tile ordering launch failed: %s", hipGetErrorString(e));
         s->order_valid = true;
+        s->ticket_clean_for = (long long)launch_no + 1;
     }
     if (dp.spp > 1 && !dp.wave_resolve) {
         e = exact ? launch_resolve_exact(st, s->sbuf, d_out, dp.n_rows * dp.width, dp.spp, dp.out_format)

@@ -151,6 +151,7 @@ enum { CNT_PRIMARY = 0, CNT_REFLECT, CNT_REFRACT, CNT_REFRACT_EXIT, CNT_SHADOW, 
        CNT_SLOTS = 16,
        CNT_SLOTS_DEV = 48 };  // development builds (-DRAYHS_PROFILE_LOOPS) also write slots 16..31: the library's own buffer holds 32
 
+static constexpr int ORDER_MAX_BLOCKS = 64;  // workgroups of the tile-ordering kernels (one 1024-entry histogram row each)
 static constexpr int TRACE_BLOCK = 256;     // threads per workgroup (4 waves)
 static constexpr int FRAME_SLOTS = 14;      // doubles per continuation frame
 static constexpr int LANE_SLOTS = 6;        // per-lane doubles kept in the global workspace besides frames (view dir, light term)

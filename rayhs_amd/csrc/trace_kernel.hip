@@ -1410,45 +1410,75 @@ RAYHS_CAT(rayhs_resolve, RAYHS_KERNEL_SUFFIX)(const double *sbuf, void *out, int
 // 0.07 ms for an average one; in scan order such chunks are still being started when the frame is nearly done, and
 // the other waves idled 12 % of the dragon frame waiting for them.  Handing the tiles out by decreasing cost --
 // longest processing time first, with the cost MEASURED on the previous frame (same view, or a neighbouring one in an
-// animation) -- leaves only cheap chunks for the end.  One workgroup: counting sort into 1024 cost classes (the
-// order inside a class does not matter), then the sorted list is dealt in groups of 8 to the 8 bands of the item
-// space (one per XCD, see trace_body), so that every band starts with its share of the slow tiles.
+// animation) -- leaves only cheap chunks for the end.  A counting sort into 1024 cost classes (the order inside a
+// class does not matter), then the sorted list is dealt in groups of 8 to the 8 bands of the item space (one per XCD,
+// see trace_body), so that every band starts with its share of the slow tiles.
+// The classes are LOGARITHMIC, 64 per binade over [2^5, 2^21) (ticks of 10 ns: 0.3 us .. 21 ms per chunk; the static
+// estimate is scaled into the same range): the class of a cost is a bit field of the float, so no pass over the costs is
+// needed to find their maximum first, and the sort is two small many-workgroup kernels -- histogram, then scan + scatter
+// -- instead of one workgroup doing three passes (0.040 ms per frame before, a tenth of the GPU time of the 0.25 ms
+// Cornell frame; the scatter alone was 65 k scattered stores issued by one compute unit).
 // Only the order in which pixels are worked on changes, never a result.
+namespace rayhs {
+constexpr int kOrderClasses = 1024, kOrderBlock = 1024;
+DEV int cost_class_raw(float cost) {  // 0 (cheapest / never measured) .. 1023; monotone in cost
+    const int e = (int)(__float_as_uint(cost) >> 17) - ((127 + 5) << 6);
+    return min(max(e, 0), kOrderClasses - 1);
+}
+}  // namespace rayhs
+// Block b counts the classes of ITS tiles (tile i belongs to block (i / 1024) % blocks in both kernels) into row b of
+// `hist`: every row is written whole, nothing needs clearing, and no global atomic is involved.  (A first version
+// added into one shared histogram and drew places from shared per-class cursors: the tiles of a frame crowd into a few
+// classes, tens of thousands of atomics landed on a handful of addresses, and the scatter took 47 us against the 29 us
+// of the one-workgroup kernel it replaced.)
 extern "C" __global__ void __launch_bounds__(1024)
-RAYHS_CAT(rayhs_order_tiles, RAYHS_KERNEL_SUFFIX)(float *cost, int n, int *order) {
-    __shared__ unsigned cls_count[1024], cls_start[1024], max_bits;
+RAYHS_CAT(rayhs_order_hist, RAYHS_KERNEL_SUFFIX)(const float *cost, int n, unsigned *hist) {
+    __shared__ unsigned local[kOrderClasses];
     const int t = threadIdx.x;
-    cls_count[t] = 0;
-    if (t == 0) max_bits = 0;
+    local[t] = 0;
     __syncthreads();
-    float m = 0.0f;
-    for (int i = t; i < n; i += 1024) m = fmaxf(m, cost[i]);
-    atomicMax(&max_bits, __float_as_uint(m));
+    for (int i = blockIdx.x * kOrderBlock + t; i < n; i += gridDim.x * kOrderBlock) atomicAdd(&local[kOrderClasses - 1 - cost_class_raw(cost[i])], 1u);  // class 0 = slowest
     __syncthreads();
-    const float scale = 1023.0f / fmaxf(__uint_as_float(max_bits), 1.0f);
-    for (int i = t; i < n; i += 1024) atomicAdd(&cls_count[1023 - min(1023, (int)(cost[i] * scale))], 1u);  // class 0 = slowest
+    hist[blockIdx.x * kOrderClasses + t] = local[t];
+}
+// Every block sums the rows (class totals, and what the blocks before it hold of each class), scans the totals, and
+// puts its own tiles in place; clears the costs it has read and (block 0) the ticket counters of the next launch.
+extern "C" __global__ void __launch_bounds__(1024)
+RAYHS_CAT(rayhs_order_tiles, RAYHS_KERNEL_SUFFIX)(float *cost, int n, int *order, const unsigned *hist, unsigned long long *next_ticket, int ticket_slots) {
+    __shared__ unsigned cls_start[kOrderClasses], mine[kOrderClasses];
+    __shared__ int top;
+    const int t = threadIdx.x;
+    unsigned total = 0, before = 0;
+    for (int b = 0; b < (int)gridDim.x; b++) {
+        const unsigned v = hist[b * kOrderClasses + t];
+        total += v;
+        before += b < (int)blockIdx.x ? v : 0u;
+    }
+    cls_start[t] = total;
+    if (t == 0) top = kOrderClasses - 1;
+    if (blockIdx.x == 0 && next_ticket != nullptr && t < ticket_slots) next_ticket[t] = 0ull;
     __syncthreads();
-    // exclusive prefix sum over the 1024 classes (Hillis-Steele)
-    const unsigned v = cls_count[t];
-    cls_start[t] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
+    if (total) atomicMin(&top, t);  // the slowest class that holds a tile
+    for (int off = 1; off < kOrderClasses; off <<= 1) {  // inclusive prefix sum (Hillis-Steele)
         const unsigned add_ = t >= off ? cls_start[t - off] : 0u;
         __syncthreads();
         cls_start[t] += add_;
         __syncthreads();
     }
-    cls_start[t] -= v;
+    mine[t] = cls_start[t] - total + before;  // where this block's tiles of class t begin
     __syncthreads();
     const int cycles = n / 64, rest = n % 64;  // sorted position p goes to band (p / 8) % 8
-    for (int i = t; i < n; i += 1024) {
-        const int c = 1023 - min(1023, (int)(cost[i] * scale));
-        const int p = (int)atomicAdd(&cls_start[c], 1u);
+    const int top_raw = kOrderClasses - 1 - top;
+    for (int i = blockIdx.x * kOrderBlock + t; i < n; i += gridDim.x * kOrderBlock) {
+        const int raw = cost_class_raw(cost[i]), c = kOrderClasses - 1 - raw;
+        const int p = (int)atomicAdd(&mine[c], 1u);
         const int g = p >> 3, band = g & 7;
         int band_begin = 0;
         for (int b = 0; b < band; b++) band_begin += cycles * 8 + min(max(rest - 8 * b, 0), 8);
-        // issue priority of the wave that will work on it: 0..3 by quarters of the slowest tile's time
-        const int prio = min(3, (int)(cost[i] * scale * (4.0f / 1024.0f)));
+        // issue priority of the wave that will work on it: 0..3 by quarters of the slowest tile's time (64 classes per
+        // binade: 3/4 of the top is 27 classes below it, 1/2 is 64, 1/4 is 128)
+        const int below = top_raw - raw;
+        const int prio = below <= 26 ? 3 : below <= 63 ? 2 : below <= 127 ? 1 : 0;
         order[band_begin + (g >> 3) * 8 + (p & 7)] = i | (prio << kTileBits);
         cost[i] = 0.0f;
     }
@@ -1562,8 +1592,8 @@ RAYHS_CAT(rayhs_static_costs, RAYHS_KERNEL_SUFFIX)(DScene sc, DCamera cam, DPara
     // weights fitted to the chunk times a measured frame records (dragon scenes, profiles/r02/static_costs.md): in units of a
     // diffuse wall tile, a tile is worth ~3 when its rays only graze the upper boxes and up to ~17 deep inside the model
     if (box_rays > 0) c += boxes_met < 40 ? 0.045f * (float)boxes_met : fminf(16.0f, 1.8f + 0.26f * (float)(boxes_met - 40));
-    if (prm.flags_dev & 1) c = (float)boxes_met;  // development: dump the raw feature (RAYHS_DUMP_TILE_COSTS)
-    cost[tile] = c;
+    if (prm.flags_dev & 1) { cost[tile] = (float)boxes_met; return; }  // development: dump the raw feature (RAYHS_DUMP_TILE_COSTS)
+    cost[tile] = c * 4096.0f;  // into the range the ordering kernels resolve (they class costs on a fixed logarithmic scale made for ticks)
 }
 
 RAYHS_DEFINE_KERNEL(rayhs_trace, false, false, unsigned short, RAYHS_WAVES_PER_EU)       // < 65536 BVH nodes
@@ -1634,8 +1664,12 @@ hipError_t RAYHS_CAT(launch_scatter_stripes, RAYHS_KERNEL_SUFFIX)(hipStream_t st
                        n_rows, stripe_rows, row_bytes, unit);
     return hipGetLastError();
 }
-hipError_t RAYHS_CAT(launch_order_tiles, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, float *cost, int n, int *order) {
-    hipLaunchKernelGGL(RAYHS_CAT(rayhs_order_tiles, RAYHS_KERNEL_SUFFIX), dim3(1), dim3(1024), 0, stream, cost, n, order);
+// aux: kOrderMaxBlocks * 1024 unsigned (one histogram row per block).  next_ticket (may be NULL): `ticket_slots` counters the
+// scatter kernel zeroes for the launch that follows on this stream.
+hipError_t RAYHS_CAT(launch_order_tiles, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, float *cost, int n, int *order, unsigned *aux, unsigned long long *next_ticket, int ticket_slots) {
+    const unsigned grid = (unsigned)std::max(1, std::min(ORDER_MAX_BLOCKS, (n + kOrderBlock - 1) / kOrderBlock));
+    hipLaunchKernelGGL(RAYHS_CAT(rayhs_order_hist, RAYHS_KERNEL_SUFFIX), dim3(grid), dim3(kOrderBlock), 0, stream, (const float *)cost, n, aux);
+    hipLaunchKernelGGL(RAYHS_CAT(rayhs_order_tiles, RAYHS_KERNEL_SUFFIX), dim3(grid), dim3(kOrderBlock), 0, stream, cost, n, order, (const unsigned *)aux, next_ticket, ticket_slots);
     return hipGetLastError();
 }
 int RAYHS_CAT(occupancy_trace, RAYHS_KERNEL_SUFFIX)(int variant, size_t lds_bytes) {

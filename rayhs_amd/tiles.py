@@ -44,9 +44,10 @@ class FrameGather:
         self.local = torch.zeros((self.pad_rows, width, channels), dtype=dtype, device=device)
         if rank == 0:
             # one allocation; the gather lands in its per-rank slices
-            self.stacked = torch.empty((world, self.pad_rows, width, channels), dtype=dtype, device=device)
+            self.stacked = torch.empty((world, self.pad_rows, width, channels), dtype=dtype, device=device) if world > 1 else None
             self.parts = [self.stacked[r] for r in range(world)] if world > 1 else None
-            self.frame = torch.empty((height, width, channels), dtype=dtype, device=device)
+            # with one rank there is nothing to gather or to put in order: the frame IS the local buffer (no copy per frame)
+            self.frame = self.local[:height] if world == 1 else torch.empty((height, width, channels), dtype=dtype, device=device)
             src_rank, src_row, dst_row = [], [], []
             for r in range(world):
                 rr = stripe_rows_of(r, world, height, stripe_rows)
@@ -75,8 +76,7 @@ class FrameGather:
 
     def gather_finish(self):
         if self.world == 1:
-            self.frame.copy_(self.local[: self.height])
-            return self.frame
+            return self.frame   # a view of `local`
         self._work.wait()  # makes the current stream wait for the collective; does not block the host
         self._work = None
         if self.rank != 0:
