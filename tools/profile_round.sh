@@ -5,7 +5,7 @@
 # one stream: the --stats rows of every kernel are then its real duration), and four PMC passes (counters in their own
 # runs, no other trace domain -- see MI355X_MICROARCH.md, HBM/rocprofv3 section).
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 wl=${2:-dragon}
 out=gpurun_out
 pre=$out/${tag}_${wl}

@@ -11,7 +11,7 @@ import collections, csv, glob, json, os, re, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 wl = sys.argv[2] if len(sys.argv) > 2 else "dragon"
 src, pre = "gpurun_out", f"gpurun_out/{tag}_{wl}"
 dst = os.path.join("profiles", tag, wl)
