@@ -1531,9 +1531,14 @@ DEV int upper_boxes_met(const DScene &sc, const DMesh &me, V3 o, V3 d) {
 }  // namespace rayhs
 extern "C" __global__ void __launch_bounds__(256)
 RAYHS_CAT(rayhs_static_costs, RAYHS_KERNEL_SUFFIX)(DScene sc, DCamera cam, DParams prm, float *cost) {
-    const int tile = blockIdx.x * 256 + threadIdx.x;
-    if (tile >= prm.n_tiles) return;
-    const int ty = tile / prm.tiles_x, tx = tile - ty * prm.tiles_x;
+    // Eight lanes per tile: lane k < 5 looks through one of the tile's five rays (k = 0: the centre ray, which also classes
+    // the surface it sees), the counts are added up across the eight lanes.  With one THREAD per tile the kernel was a
+    // long serial chain on 512 waves, half the chip idle: 0.14 ms in front of the first frame, more than half of the 0.25 ms
+    // Cornell frame it was there to speed up.
+    const int tile = (blockIdx.x * 256 + threadIdx.x) >> 3, k_lane = threadIdx.x & 7;
+    const bool live = tile < prm.n_tiles;  // (no early return: the lanes of a tile meet again in the shuffles below)
+    if (!live && __ballot(live) == 0ull) return;
+    const int ty = (live ? tile : 0) / prm.tiles_x, tx = (live ? tile : 0) - ty * prm.tiles_x;
     auto image_row = [&](int lrow) {  // local row -> image row (stripe interleave, as in the trace kernel)
         if (prm.stripe_count == 1 && prm.stripe_map == nullptr) return prm.row0 + lrow;
         const int s_local = lrow / prm.stripe_rows, in_stripe = lrow - s_local * prm.stripe_rows;
@@ -1545,7 +1550,7 @@ RAYHS_CAT(rayhs_static_costs, RAYHS_KERNEL_SUFFIX)(DScene sc, DCamera cam, DPara
     const double inf = __builtin_inf();
     float c = 1.0f;
     int box_rays = 0, boxes_met = 0;
-    for (int k = 0; k < 5; k++) {
+    for (int k = k_lane; k < 5 && live; k += 8) {  // (one pass: this lane's ray)
         // sample offsets reach half a pixel beyond the pixel corners (src/RayHs.hs:178-188): look half a pixel wider
         const double fx = k == 0 ? 0.5 * (double)(x0 + x1) : ((k & 1) ? (double)x0 - 0.5 : (double)x1 + 0.5);
         const double fy = k == 0 ? 0.5 * (ytop + ybot) : ((k & 2) ? ytop - 0.5 : ybot + 0.5);
@@ -1589,6 +1594,12 @@ RAYHS_CAT(rayhs_static_costs, RAYHS_KERNEL_SUFFIX)(DScene sc, DCamera cam, DPara
                 if (sc.meshes[m].froot != FNODE_NONE && hits_mesh_box(sc.meshes[m], add(p, scl(1e-6, rf)), rf, inf)) { c += 3.0f; break; }
         }
     }
+    for (int off = 1; off < 8; off <<= 1) {  // the eight lanes of a tile are neighbours in the wave
+        box_rays += __shfl_xor(box_rays, off);
+        boxes_met += __shfl_xor(boxes_met, off);
+        c += __shfl_xor(c, off) - 1.0f;  // (every lane started from the base cost 1; only lane 0 added to it)
+    }
+    if (!live || k_lane != 0) return;
     // weights fitted to the chunk times a measured frame records (dragon scenes, profiles/r02/static_costs.md): in units of a
     // diffuse wall tile, a tile is worth ~3 when its rays only graze the upper boxes and up to ~17 deep inside the model
     if (box_rays > 0) c += boxes_met < 40 ? 0.045f * (float)boxes_met : fminf(16.0f, 1.8f + 0.26f * (float)(boxes_met - 40));
@@ -1649,7 +1660,7 @@ hipError_t RAYHS_CAT(launch_resolve, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, co
     return hipGetLastError();
 }
 hipError_t RAYHS_CAT(launch_static_costs, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, const DScene &sc, const DCamera &cam, const DParams &prm, float *cost) {
-    hipLaunchKernelGGL(RAYHS_CAT(rayhs_static_costs, RAYHS_KERNEL_SUFFIX), dim3((unsigned)((prm.n_tiles + 255) / 256)), dim3(256), 0, stream, sc, cam, prm, cost);
+    hipLaunchKernelGGL(RAYHS_CAT(rayhs_static_costs, RAYHS_KERNEL_SUFFIX), dim3((unsigned)((prm.n_tiles + 31) / 32)), dim3(256), 0, stream, sc, cam, prm, cost);  // 8 lanes per tile
     return hipGetLastError();
 }
 hipError_t RAYHS_CAT(launch_scatter_stripes, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, const void *src, void *dst, const int *stripe_map, int n_rows,
