@@ -90,6 +90,14 @@ def profile_counters(workload, kernel_ms):
         "wave_wait_frac": c.get("SQ_WAIT_ANY_per_wave_cycle"),
         "salu_per_valu": c.get("salu_per_valu"),
         "valu_insts_per_launch": c.get("SQ_INSTS_VALU"),
+        # round 3's instruction-mix pass: what the vector PIPE is occupied for (fp64 at half rate), what a wave does with its life
+        "valu_pipe_frac": c.get("valu_pipe_frac"),
+        "valu_f64_share_of_insts": c.get("valu_f64_share_of_insts"),
+        "fp64_tflops_issued": (c["fp64_flops_per_launch"] / sec / 1e12) if "fp64_flops_per_launch" in c else None,
+        "fp64_peak_tflops": 78.6,
+        "wave_issuing_frac": c.get("SQ_ACTIVE_INST_ANY_per_wave_cycle"),
+        "wave_waitcnt_frac": c.get("SQ_WAIT_INST_ANY_per_wave_cycle"),
+        "branches_per_valu": c.get("branches_per_valu"),
     }
 
 
@@ -332,17 +340,22 @@ def main():
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         # The contract line: algorithmic bytes per launch / kernel time against the HBM peak.  The scene is
         # cache-resident, so `achieved` is served by L1 / scalar cache / L2 and can exceed the HBM peak: it is a work rate,
-        # not a bandwidth.  What binds the kernel is VALU issue; the counter-based fields next to it say how hard, and
-        # how little of the HBM bandwidth is really used.
+        # not a bandwidth.  What binds the kernel is the serial latency of its waves at 4 waves/SIMD; the counter-based
+        # fields next to it say how the waves spend their time, and how little of the HBM bandwidth is really used.
         src, ctr = profile_counters(args.workload, kernel_ms) if world == 1 else ({"profile": None, "matches_this_kernel": False}, None)
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": ctr["traffic"] if ctr else None, "algorithmic_bytes_per_launch": alg,
-                    "bound_actual": "valu-issue: the fp64 VALU pipe, not HBM -- the whole scene stays in cache; see valu_busy, valu_lane_util, hbm_traffic_frac",
+                    "bound_actual": "wave latency at 4 waves/SIMD: neither HBM (3 % of peak, the scene stays in cache) nor the vector pipe (valu_pipe_frac) "
+                                    "is full; a wave issues ~38 % of its life (wave_issuing_frac), waits at s_waitcnt ~27 % (wave_waitcnt_frac); "
+                                    "valu_busy is the waves' VALU issue time, 4 cycles per instruction, not pipe occupancy (DESIGN.md section 4)",
                     "hbm_traffic_frac": ctr and ctr["hbm_traffic_frac"], "hbm_read_frac": ctr and ctr["hbm_read_frac"],
                     "hbm_write_bytes": ctr and ctr["hbm_write_bytes"], "l2_hit_rate": ctr and ctr["l2_hit_rate"],
                     "valu_busy": ctr and ctr["valu_busy"], "valu_lane_util": ctr and ctr["valu_lane_util"],
                     "wave_wait_frac": ctr and ctr["wave_wait_frac"], "salu_per_valu": ctr and ctr["salu_per_valu"],
-                    "valu_insts_per_launch": ctr and ctr["valu_insts_per_launch"], "counters_from": src}
+                    "valu_insts_per_launch": ctr and ctr["valu_insts_per_launch"],
+                    **({k: ctr[k] for k in ("valu_pipe_frac", "valu_f64_share_of_insts", "fp64_tflops_issued", "fp64_peak_tflops", "wave_issuing_frac",
+                                            "wave_waitcnt_frac", "branches_per_valu")} if ctr else {}),
+                    "counters_from": src}
         out = {
             "metric": "Mrays/s", "value": rays_frame * args.steps / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
