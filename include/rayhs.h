@@ -182,6 +182,12 @@ uint32_t rayhs_sizeof(int which);
 /* number of visible HIP devices (0 if none or the runtime is unusable) */
 int rayhs_device_count(void);
 
+/* Optional: bring up the HIP runtime, the context of `device` and the kernels' code object now, e.g. from a second host
+ * thread while the first one is still decoding the scene -- the first rayhs_scene_create of a process otherwise spends
+ * 0.1-0.2 s doing exactly that ("end to end").  Thread-safe; calling it more than once, or never,
+ * changes nothing but timing.  RAYHS_ERR_NO_DEVICE / RAYHS_ERR_INVALID as for rayhs_scene_create. */
+int rayhs_device_prepare(int device);
+
 /* Copies the description into device `device` (HBM-resident until destroy).  Every entry point that takes a
  * scene makes that device current on the calling thread (hipSetDevice) and leaves it current. */
 int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayhs_scene **out);

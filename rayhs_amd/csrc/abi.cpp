@@ -111,6 +111,16 @@ extern "C" int rayhs_device_count(void) {
     return n;
 }
 
+extern "C" int rayhs_device_prepare(int device) {
+    int ndev = rayhs_device_count();
+    if (ndev <= 0) return set_error(RAYHS_ERR_NO_DEVICE, "no HIP device available (librayhs_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return set_error(RAYHS_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(nullptr));                       // creates the context
+    (void)occupancy_trace_exact(0, 40 * 1024);       // resolves the kernel: loads the code object onto this device
+    return RAYHS_OK;
+}
+
 // ---------------------------------------------------------------- validation
 static int check_desc(const rayhs_scene_desc *d, int &tree_depth) {
     if (!d) return set_error(RAYHS_ERR_INVALID, "scene description is NULL");

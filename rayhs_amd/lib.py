@@ -75,6 +75,7 @@ SYMBOLS = [
     ("rayhs_abi_version", C.c_int, []),
     ("rayhs_sizeof", C.c_uint32, [C.c_int]),
     ("rayhs_device_count", C.c_int, []),
+    ("rayhs_device_prepare", C.c_int, [C.c_int]),
     ("rayhs_scene_create", C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
     ("rayhs_scene_destroy", None, [C.c_void_p]),
     ("rayhs_render_rows", C.c_int, [C.POINTER(RenderParams)]),

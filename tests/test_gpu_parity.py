@@ -400,6 +400,15 @@ def test_multi_device_ragged_frames_row_ranges_and_counters(w, h, stripe, device
     single.close()
 
 
+def test_device_prepare_is_optional_and_idempotent():
+    # rayhs_device_prepare only moves start-up cost (runtime, context, code object) to where the caller wants it
+    lib = L.load()
+    assert lib.rayhs_device_prepare(0) == L.OK and lib.rayhs_device_prepare(0) == L.OK
+    assert lib.rayhs_device_prepare(lib.rayhs_device_count()) == L.ERR_INVALID
+    img, _ = rayhs_amd.ray_trace_file("scenes/cornell_96.json")
+    assert np.array_equal(img, np.load(os.path.join(GOLD, "cornell_96.npy")))
+
+
 def test_cli_gpus_option_writes_the_same_file(tmp_path):
     a, b = tmp_path / "one.ppm", tmp_path / "multi.ppm"
     r = rayhs_amd.run_cli([f"-o{a}", "--spp=2", "scenes/dragon_superlow_96.json"], cwd=ROOT)

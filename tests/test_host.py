@@ -295,6 +295,7 @@ def test_compute_entry_points_refuse_without_gpu():
     rc = L.load().rayhs_scene_create(C.byref(rd.scene_desc), 0, C.byref(h))
     assert rc == L.ERR_NO_DEVICE and not h.value
     assert b"no CPU fallback" in L.load().rayhs_last_error()
+    assert L.load().rayhs_device_prepare(0) == L.ERR_NO_DEVICE   # the optional warm-up call reports the same thing
     with pytest.raises(L.RayhsError):
         rayhs_amd.ray_trace_file("scenes/cornell_96.json")
     r = rayhs_amd.run_cli(["-o/tmp/_x.ppm", "scenes/cornell_96.json"], cwd=ROOT)
