@@ -33,8 +33,11 @@ extern "C" {
  * caller compiled against version 1 that asks for stats must be rebuilt against this header; it cannot be served
  * by a version-2 library (callers that pass stats = NULL are unaffected).  A host that mirrors the structs by hand
  * (a Haskell Storable instance, ctypes) checks its layout with rayhs_sizeof() at start-up and the version with
- * rayhs_abi_version(); rayhs_amd/lib.py refuses a library that answers differently. */
-#define RAYHS_ABI_VERSION 2
+ * rayhs_abi_version(); rayhs_amd/lib.py refuses a library that answers differently.
+ * Version 3 changed no struct: it ADDED rayhs_sizeof(), rayhs_device_prepare() and RAYHS_FLAG_POW5_SQMUL, and render
+ * calls now fail with RAYHS_ERR_INVALID on flag bits the library does not know (RAYHS_FLAG_ALL) instead of ignoring
+ * them -- a version-2 library would have rendered the flat-product reading of x ^ 5 for a caller that asked for the other. */
+#define RAYHS_ABI_VERSION 3
 
 typedef enum {
     RAYHS_OK = 0,
@@ -138,6 +141,7 @@ enum { RAYHS_OUT_F32 = 0, RAYHS_OUT_F64 = 1, RAYHS_OUT_I16 = 2 };
                                   default is the flat product x*x*x*x*x that GHC's RULES "^5/Int" produce under -O (the
                                   reference builds with -O2, build.sh:1).  No GHC was available to confirm which one the
                                   reference binary runs; they differ by an ulp or two of the Fresnel factor */
+#define RAYHS_FLAG_ALL (RAYHS_FLAG_FMA | RAYHS_FLAG_EXHAUSTIVE | RAYHS_FLAG_COUNT | RAYHS_FLAG_POW5_SQMUL) /* any other bit: RAYHS_ERR_INVALID */
 
 /* Rendering (src/RayHs.hs:41-45) plus the tiling needed to shard a frame.
  * Rows row0 <= y < row1 are considered; of those this call renders the rows

@@ -3,7 +3,7 @@
     python oracle/second/check_second.py            # asserts + writes tests/golden/second_*.npy
 
 (a) asserts that oracle/second/rayhs_second.py (plain Python, written from the Haskell alone) and
-    oracle/rayhs_oracle.c (the C oracle every parity test uses) produce BIT-IDENTICAL images on the six
+    oracle/rayhs_oracle.c (the C oracle every parity test uses) produce BIT-IDENTICAL images on the seven
     golden frames (whole) and on pixel windows of the four BASELINE configurations at their own size and
     sample count -- every material, both light kinds, both projections, all transform kinds, textures,
     the mesh tree, and the multi-sample path;
@@ -29,8 +29,9 @@ from oracle.second import rayhs_second as S  # noqa: E402
 
 # name: (scene, width, height, spp, rows, cols)   -- rows / cols None = the whole frame
 CASES = {
-    # the six golden frames of tests/golden/make_golden.py, whole
+    # the seven golden frames of tests/golden/make_golden.py, whole
     "cornell_96": ("scenes/cornell_96.json", 96, 96, 1, None, None),
+    "cornell_256": ("scenes/cornell_256.json", 256, 256, 1, None, None),   # BASELINE configs[0]
     "dragon_superlow_96": ("scenes/dragon_superlow_96.json", 96, 96, 1, None, None),
     "dragon_superlow_96_spp4": ("scenes/dragon_superlow_96.json", 96, 96, 4, None, None),
     "outscene_128x72": ("scenes/outscene_128x72.json", 128, 72, 1, None, None),

@@ -557,6 +557,7 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     if (p->width <= 0 || p->height <= 0 || p->max_depth < 0 || p->spp < 1) return set_error(RAYHS_ERR_INVALID, "bad width/height/maxDepth/spp");
     if (p->row1 > p->height) return set_error(RAYHS_ERR_INVALID, "row1 beyond the image");
     if (p->out_format < RAYHS_OUT_F32 || p->out_format > RAYHS_OUT_I16) return set_error(RAYHS_ERR_INVALID, "bad out_format");
+    if (p->flags & ~RAYHS_FLAG_ALL) return set_error(RAYHS_ERR_INVALID, "unknown flag bits 0x%x (this library knows 0x%x)", p->flags & ~RAYHS_FLAG_ALL, RAYHS_FLAG_ALL);
     if (cam->proj_kind != RAYHS_PROJ_ORTHOGRAPHIC && cam->proj_kind != RAYHS_PROJ_PERSPECTIVE) return set_error(RAYHS_ERR_INVALID, "bad projection kind");
     int rows = sl ? sl->rows : rayhs_render_rows(p);
     if (rows < 0) return rows;
@@ -747,19 +748,34 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
             std::fclose(f);
         }
     }
+    if (dp.tile_order != nullptr && std::getenv("RAYHS_DUMP_TILE_ORDER")) {  // development / tests: the work order THIS frame was given
+        std::vector<int32_t> h((size_t)dp.n_tiles);
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(h.data(), s->order_dev, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (FILE *f = std::fopen(std::getenv("RAYHS_DUMP_TILE_ORDER"), "ab")) {
+            int hdr[4] = {dp.n_tiles, dp.tiles_x, static_order ? 1 : 0, 0};  // [2]: 1 = static estimate, 0 = measured chunk times
+            std::fwrite(hdr, sizeof hdr, 1, f);
+            std::fwrite(h.data(), sizeof(int32_t), h.size(), f);
+            std::fclose(f);
+        }
+    }
     if (record_costs) {  // this frame's chunk times -> the next frame's tile order
         e = exact ? launch_order_tiles_exact(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, next_ticket, kTicketSlots) : launch_order_tiles_fast(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, next_ticket, kTicketSlots);
         if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "tile ordering launch failed: %s", hipGetErrorString(e));
         s->order_valid = true;
-        s->ticket_clean_for = (long long)launch_no + 1;
     }
     if (dp.spp > 1 && !dp.wave_resolve) {
         e = exact ? launch_resolve_exact(st, s->sbuf, d_out, dp.n_rows * dp.width, dp.spp, dp.out_format)
                   : launch_resolve_fast(st, s->sbuf, d_out, dp.n_rows * dp.width, dp.spp, dp.out_format);
         if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "resolve kernel launch failed: %s", hipGetErrorString(e));
     }
+    // (ticket_clean_for promises that the next launch's counters are zeroed by work ORDERED BEHIND last_done: it is set
+    // only once that event has been recorded, together with the stream it was recorded on, so that an error return in
+    // between leaves the next launch to zero its own counters)
+    s->ticket_clean_for = -1;
     HIP_TRY(hipEventRecord(s->last_done, st));
     s->last_stream = st; s->have_last = true;
+    if (record_costs) s->ticket_clean_for = (long long)launch_no + 1;
     return RAYHS_OK;
 }
 
@@ -919,12 +935,22 @@ extern "C" int rayhs_multi_create(const rayhs_scene_desc *desc, const int *devic
         codes[i] = rc;
         if (rc) messages[i] = g_error;  // (the error text is thread-local: carried back to the calling thread below)
     };
-    if (n == 1 || std::getenv("RAYHS_MULTI_SERIAL_CREATE")) {
+    // One thread per device is opt-in (RAYHS_MULTI_PARALLEL_CREATE): concurrent peer enabling across DISTINCT devices has
+    // not run on hardware yet (every box this build has had shows one GPU; tests/test_gpu_parity.py has the two-GPU test
+    // that will).  A thread that cannot be started must not take the process down through the extern "C" boundary:
+    // whatever was started is joined and the remaining devices are brought up on the calling thread.
+    if (n == 1 || !std::getenv("RAYHS_MULTI_PARALLEL_CREATE") || std::getenv("RAYHS_MULTI_SERIAL_CREATE")) {
         for (size_t i = 0; i < n; i++) bring_up(i);
     } else {
         std::vector<std::thread> workers;
-        for (size_t i = 0; i < n; i++) workers.emplace_back(bring_up, i);
+        size_t started = 0;
+        try {
+            workers.reserve(n);
+            for (; started < n; started++) workers.emplace_back(bring_up, started);
+        } catch (...) {  // std::system_error (no thread to be had) or bad_alloc
+        }
         for (auto &w : workers) w.join();
+        for (size_t i = started; i < n; i++) bring_up(i);
     }
     for (size_t i = 0; i < n; i++)
         if (codes[i]) { g_error = messages[i]; return fail(codes[i]); }

@@ -297,6 +297,12 @@ DEV float f32_up(double v) {  // smallest float >= v (v >= 0 here)
     return f;
 }
 
+#ifndef RAYHS_GROUP_COS
+#define RAYHS_GROUP_COS 0.9f
+#endif
+#ifndef RAYHS_GROUP_MAX
+#define RAYHS_GROUP_MAX 64
+#endif
 constexpr int kTileBits = 28, kTileMask = (1 << kTileBits) - 1;  // tile-order entry: tile index | issue-priority class << 28
 
 // ---- per-lane reads of scene records: uniform base (an SGPR pair) + 32-bit byte offset, so that the load uses the
@@ -735,24 +741,35 @@ struct Tracer {
             // ends when its last lane is done, after about as many visits as its longest ray needed.  Boxes only cull, the
             // triangle tests and the tie rule are the per-lane path's, so the answer is the same.  Waves whose rays
             // neither share an octant nor form a narrow cone (reflections off the model) keep the per-lane walk below.
-            const unsigned long long nx = em & __ballot(ix < 0.0f), ny = em & __ballot(iy < 0.0f), nz = em & __ballot(iz < 0.0f);
-#ifdef RAYHS_PACKET_ALWAYS
-            if (true) {
-#else
-            // ... or into a narrow cone (within ~25 degrees) around the first entering ray's direction: shadow rays
-            // converging on a near light straddle an axis without being any less of a bundle.  (Looking at the cone only
-            // when the octants disagree saved its twenty vector instructions for most waves and gained nothing.)
-            const int lead_lane = __ffsll((unsigned long long)em) - 1;
+            // The entering lanes are walked as a SEQUENCE of packets: the first lane not yet walked leads, and every remaining
+            // lane whose direction lies within a cone around the leader's joins its packet (all remaining lanes when they
+            // share an octant).  A coherent wave is one packet; a wave whose lanes hold rays of several kinds (shadow rays
+            // towards two lights, reflections beside shadow rays) falls apart into one packet per bundle.
+            unsigned long long g_rem = em, m_occ = __ballot(occ);
             const float dx = (float)r.d.x, dy = (float)r.d.y, dz = (float)r.d.z;
-            const float lx = __shfl(dx, lead_lane), ly = __shfl(dy, lead_lane), lz = __shfl(dz, lead_lane);
-            const float cosine = (dx * lx + dy * ly + dz * lz) * __builtin_amdgcn_rsqf((dx * dx + dy * dy + dz * dz) * (lx * lx + ly * ly + lz * lz));
-            const bool cone = (em & ~__ballot(cosine > 0.9f)) == 0ull;
-            if (cone || ((nx == 0ull || nx == em) && (ny == 0ull || ny == em) && (nz == 0ull || nz == em))) {
+            const float dn = dx * dx + dy * dy + dz * dz;
+            int g_count = 0;
+            while (g_rem != 0ull) {
+                unsigned long long g_grp;
+                {
+                    const unsigned long long nx = g_rem & __ballot(ix < 0.0f), ny = g_rem & __ballot(iy < 0.0f), nz = g_rem & __ballot(iz < 0.0f);
+                    const bool same_octant = (nx == 0ull || nx == g_rem) && (ny == 0ull || ny == g_rem) && (nz == 0ull || nz == g_rem);
+                    const int lead_lane = __ffsll((unsigned long long)g_rem) - 1;
+                    const float lx = __shfl(dx, lead_lane), ly = __shfl(dy, lead_lane), lz = __shfl(dz, lead_lane);
+                    const float cosine = (dx * lx + dy * ly + dz * lz) * __builtin_amdgcn_rsqf(dn * (lx * lx + ly * ly + lz * lz));
+                    g_grp = (g_rem & __ballot(cosine > RAYHS_GROUP_COS)) | (1ull << lead_lane);
+                    g_count++;
+                    if (same_octant || g_count >= RAYHS_GROUP_MAX) g_grp = g_rem;
+#ifndef RAYHS_PACKET_GROUPS
+                    if (g_grp != g_rem) break;  // not one bundle: the per-lane walk below
 #endif
+                }
+                g_rem &= ~g_grp;
+                if (COUNT && __builtin_amdgcn_inverse_ballot_w64(g_grp)) { LOOP_TICK(42); }
+                {
                 const stack_ptr wstack = stack - (int)(__lane_id());  // lane 0's column serves as the wave's stack
                 // (lane yes/no values are wave masks in scalar registers, as in begin())
-                unsigned long long m_live = em;
-                unsigned long long m_occ = __ballot(occ);
+                unsigned long long m_live = g_grp;
                 const unsigned long long m_shadow_lanes = __ballot(shadow), m_point_lanes = __ballot(point_light);
                 // (Requesting the next node's record before the leaves of the current visit are tested -- the scalar-cache round
                 // trip beside the triangle tests instead of after them -- was tried: the second record's 16 scalar registers on
@@ -827,11 +844,13 @@ struct Tracer {
                     cur = next;
                     if (m_live == 0ull) break;
                 }
-                occ = __builtin_amdgcn_inverse_ballot_w64(m_occ);
-                TIME_ADD(13);
-                continue;
+                }
             }
+            occ = __builtin_amdgcn_inverse_ballot_w64(m_occ);
+            TIME_ADD(13);
+            if (g_rem == 0ull) continue;
 #endif
+#ifndef RAYHS_PACKET_GROUPS
             if (enter) w.t_cur = me.froot;
             TIME_ADD(12);
             while (true) {
@@ -896,6 +915,7 @@ struct Tracer {
                 TIME_ADD(14);
                 if (__ballot(w.traversing()) == 0ull) break;
             }
+#endif
         }
     }
 };
@@ -1536,8 +1556,8 @@ RAYHS_CAT(rayhs_static_costs, RAYHS_KERNEL_SUFFIX)(DScene sc, DCamera cam, DPara
     // long serial chain on 512 waves, half the chip idle: 0.14 ms in front of the first frame, more than half of the 0.25 ms
     // Cornell frame it was there to speed up.
     const int tile = (blockIdx.x * 256 + threadIdx.x) >> 3, k_lane = threadIdx.x & 7;
-    const bool live = tile < prm.n_tiles;  // (no early return: the lanes of a tile meet again in the shuffles below)
-    if (!live && __ballot(live) == 0ull) return;
+    const bool live = tile < prm.n_tiles;  // the same for the eight lanes of a tile (they meet again in the shuffles below)
+    if (__ballot(live) == 0ull) return;    // the whole wave is past the last tile (the ballot is evaluated by every lane)
     const int ty = (live ? tile : 0) / prm.tiles_x, tx = (live ? tile : 0) - ty * prm.tiles_x;
     auto image_row = [&](int lrow) {  // local row -> image row (stripe interleave, as in the trace kernel)
         if (prm.stripe_count == 1 && prm.stripe_map == nullptr) return prm.row0 + lrow;

@@ -103,7 +103,7 @@ SYMBOLS = [
     ("rayhs_sample01", C.c_double, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
 ]
 
-ABI_VERSION = 2   # RAYHS_ABI_VERSION this binding was written against
+ABI_VERSION = 3   # RAYHS_ABI_VERSION this binding was written against
 _LIB = None
 
 
@@ -122,14 +122,23 @@ def load():
             raise ImportError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
                               "(hipcc --offload-arch=gfx950); rayhs_amd has no CPU fallback")
         lib = C.CDLL(LIB_PATH)
+        # the structs below are hand-written mirrors: refuse a library of another ABI version or another layout
+        # instead of letting it write past them (version 2 grew rayhs_stats, version 3 added entry points;
+        # include/rayhs.h, "ABI history").  The version is asked FIRST: an older library lacks symbols bound below.
+        try:
+            lib.rayhs_abi_version.restype = C.c_int
+            found = lib.rayhs_abi_version()
+        except AttributeError:
+            found = "none (no rayhs_abi_version)"
+        if found != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} implements ABI version {found}, this binding needs {ABI_VERSION}: rebuild it")
         for name, res, args in SYMBOLS:
-            f = getattr(lib, name)
+            try:
+                f = getattr(lib, name)
+            except AttributeError:
+                raise ImportError(f"{LIB_PATH} does not export {name} (declared in include/rayhs.h): rebuild it") from None
             f.restype = res
             f.argtypes = args
-        # the structs below are hand-written mirrors: refuse a library of another ABI version or another layout
-        # instead of letting it write past them (version 2 grew rayhs_stats; include/rayhs.h, "ABI history")
-        if lib.rayhs_abi_version() != ABI_VERSION:
-            raise ImportError(f"{LIB_PATH} implements ABI version {lib.rayhs_abi_version()}, this binding needs {ABI_VERSION}: rebuild it")
         for which, (name, cls) in enumerate((("rayhs_scene_desc", SceneDesc), ("rayhs_camera", Camera),
                                              ("rayhs_render_params", RenderParams), ("rayhs_stats", Stats))):
             if lib.rayhs_sizeof(which) != C.sizeof(cls):

@@ -21,6 +21,7 @@ OUT = os.path.join(ROOT, "tests", "golden")
 # (name, scene file, spp)
 CASES = [
     ("cornell_96", "scenes/cornell_96.json", 1),
+    ("cornell_256", "scenes/cornell_256.json", 1),   # BASELINE configs[0]: data/cornellBox.json at 256x256, maxDepth 3
     ("dragon_superlow_96", "scenes/dragon_superlow_96.json", 1),
     ("dragon_superlow_96_spp4", "scenes/dragon_superlow_96.json", 4),
     ("outscene_128x72", "scenes/outscene_128x72.json", 1),

@@ -49,7 +49,7 @@ BOTH_KERNELS = pytest.mark.parametrize("flags", [PRODUCTION, COUNTING], ids=["pr
 
 
 @BOTH_KERNELS
-@pytest.mark.parametrize("name", ["cornell_96", "dragon_superlow_96", "dragon_superlow_96_spp4", "transform_64"])
+@pytest.mark.parametrize("name", ["cornell_96", "cornell_256", "dragon_superlow_96", "dragon_superlow_96_spp4", "transform_64"])
 def test_bit_exact_against_golden_and_oracle(name, flags):
     m = META[name]
     img, st = rayhs_amd.ray_trace_file(m["scene"], spp=m["spp"], seed=m["seed"], flags=flags)
@@ -730,6 +730,50 @@ def test_first_frame_static_order_is_the_same_image_and_close_to_steady_state(mo
     # first frame far more -- fails the test; the measured ratio, 1.00-1.13, is evidence: tools/first_frame.py, profiles/)
     assert sorted(firsts)[1] < 2.0 * sorted(steady)[len(steady) // 2], (firsts, steady)
     _assert_frame_matches_digest(img0, "dragon_low")
+
+
+def _leading_tiles(order, share):
+    """The tiles at the head of a work order: it is dealt in groups of 8 over 8 bands (rayhs_order_tiles), so the
+    slowest `share` of the frame is the first `share` of every band."""
+    n = len(order)
+    cycles, rest = divmod(n, 64)
+    lead, begin = [], 0
+    for b in range(8):
+        size = cycles * 8 + min(max(rest - 8 * b, 0), 8)
+        lead.extend(order[begin:begin + int(size * share)])
+        begin += size
+    assert begin == n
+    return set(int(t) for t in lead)
+
+
+def test_first_frame_static_order_is_a_permutation_that_leads_with_the_slow_tiles(monkeypatch, tmp_path):
+    # not a timing: the order the first frame was GIVEN (static estimate -> rayhs_order_hist / rayhs_order_tiles) is read
+    # back and must (a) hold every tile exactly once and (b) start with the tiles the second frame's MEASURED order starts
+    # with -- a broken estimate or ordering kernel degrades to scan order, where that overlap is the share itself (5 %)
+    dump = tmp_path / "order.bin"
+    monkeypatch.setenv("RAYHS_DUMP_TILE_ORDER", str(dump))
+    r = build_rendering("scenes/dragon_low_1080p.json")
+    for _ in range(2):
+        r.ray_trace(spp=4, out_format=L.OUT_F32)
+    r.close()
+    raw = np.fromfile(dump, dtype=np.int32)
+    n = int(raw[0])
+    assert n == 240 * 135 and len(raw) == 2 * (4 + n)
+    recs = [(raw[k * (4 + n):k * (4 + n) + 4], raw[k * (4 + n) + 4:(k + 1) * (4 + n)] & 0x0FFFFFFF) for k in range(2)]
+    assert recs[0][0][2] == 1 and recs[1][0][2] == 0          # static estimate first, measured chunk times second
+    for _, order in recs:
+        assert np.array_equal(np.sort(order), np.arange(n))   # a permutation of the tiles
+    static_lead, measured_lead = _leading_tiles(recs[0][1], 0.05), _leading_tiles(recs[1][1], 0.15)
+    overlap = len(static_lead & measured_lead) / len(static_lead)
+    assert overlap > 0.5, overlap
+
+
+def test_unknown_flag_bits_are_refused():
+    r = build_rendering("scenes/cornell_96.json")
+    with pytest.raises(L.RayhsError) as e:
+        r.ray_trace(flags=0x100)
+    assert e.value.code == L.ERR_INVALID and "unknown flag" in e.value.message
+    r.close()
 
 
 def test_very_deep_recursion_limit_runs_on_a_smaller_grid(tmp_path):

@@ -373,7 +373,7 @@ def test_sampler_known_answers_and_range():
     assert v.min() >= 0 and v.max() < 1 and abs(v.mean() - 0.5) < 0.02
 
 
-@pytest.mark.parametrize("name", ["cornell_96", "dragon_superlow_96", "dragon_superlow_96_spp4", "outscene_128x72",
+@pytest.mark.parametrize("name", ["cornell_96", "cornell_256", "dragon_superlow_96", "dragon_superlow_96_spp4", "outscene_128x72",
                                   "transform_64", "texture_earth_96"])
 def test_oracle_reproduces_golden_fixture(name):
     meta = json.load(open(os.path.join(GOLD, "golden.json")))[name]
