@@ -16,10 +16,15 @@ are provably irrelevant -- zero light term -- and therefore skipped).  The frame
 scaling is "strong".
 
 Extra objects on the JSON line:
-  roofline     algorithmic bytes of ONE launch (rank 0) / its mean HIP-event
-               duration, against the 8 TB/s HBM peak.  Bytes per unit are
-               SURVEY.md 8(d)'s: 32 B per box test, 36 B per triangle test, 40 B per
-               plane/sphere test, 60 B per shaded hit, 12 B per pixel.
+  roofline     the roof that BINDS this kernel: instruction issue.  achieved = issue slots the
+               trace kernel consumes per second (instructions of one launch from the committed
+               rocprofv3 counter passes of this very kernel source, priced in SIMD-cycles by
+               tools/micro/issue_rates.hip: 1 per instruction, 1.93 per fp64 add/mul/fma, 6 per
+               fp64 rcp/rsq/sqrt) / the launch's mean HIP-event duration measured here; peak =
+               1024 SIMDs x 2.4 GHz.  `hbm_contract` keeps SURVEY.md 8(d)'s figures: algorithmic
+               bytes (32 B per box test, 36 B per triangle test, 40 B per plane/sphere test, 60 B
+               per shaded hit, 12 B per pixel) / the same duration against the 8 TB/s HBM peak --
+               a work rate served by the caches (the scene is 13 MB), not a bandwidth.
   cpu_baseline the CPU oracle (a C port of the reference algorithm: exhaustive
                traversal, recursive shading) timed on this host on a bounded sample
                of the same frame.  Reported, not the target.
@@ -46,6 +51,11 @@ STRIPE_ROWS = 8
 # behind the next frame's trace (N > 1), one on a single GPU (two buy nothing there and blur a profiler's per-kernel rows)
 IN_FLIGHT = int(os.environ.get("RAYHS_BENCH_IN_FLIGHT", "0")) or (2 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 1)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+# issue roof (same guide: 256 CUs x 4 SIMDs, 2400 MHz max clock; one instruction per SIMD-cycle with all wave slots occupied,
+# profiles/r04/micro/issue_rates.txt)
+N_SIMDS, MAX_CLOCK_GHZ = 1024, 2.4
+ISSUE_PEAK_GSLOTS = N_SIMDS * MAX_CLOCK_GHZ
+WAVE_CADENCE_CYCLES = 8.3  # cycles between two instructions of ONE wave that shares its SIMD (mixed scalar / vector code, 2..8 waves per SIMD: same file)
 
 
 def algorithmic_bytes(st):
@@ -98,6 +108,12 @@ def profile_counters(workload, kernel_ms):
         "wave_issuing_frac": c.get("SQ_ACTIVE_INST_ANY_per_wave_cycle"),
         "wave_waitcnt_frac": c.get("SQ_WAIT_INST_ANY_per_wave_cycle"),
         "branches_per_valu": c.get("branches_per_valu"),
+        # round 4: the issue roof (tools/summarize_profiles.py) and the scalar / instruction cache hit rates
+        "insts_per_launch": c.get("insts_per_launch"),
+        "issue_slots_per_launch": c.get("issue_slots_per_launch"),
+        "waves_per_simd": waves,
+        "scalar_dcache_hit_rate": c.get("scalar_dcache_hit_rate"),
+        "scalar_icache_hit_rate": c.get("scalar_icache_hit_rate"),
     }
 
 
@@ -338,16 +354,35 @@ def main():
             raise SystemExit("bench.py: the rendered frame differs from the oracle's frame digest (tests/golden/frame_digests.json)")
         alg = algorithmic_bytes(mine)
         achieved = alg / (kernel_ms * 1e-3) / 1e9
-        # The contract line: algorithmic bytes per launch / kernel time against the HBM peak.  The scene is
-        # cache-resident, so `achieved` is served by L1 / scalar cache / L2 and can exceed the HBM peak: it is a work rate,
-        # not a bandwidth.  What binds the kernel is the serial latency of its waves at 4 waves/SIMD; the counter-based
-        # fields next to it say how the waves spend their time, and how little of the HBM bandwidth is really used.
+        # roofline = the roof that binds (instruction issue, frac <= 1); hbm_contract inside it = SURVEY.md 8(d)'s line:
+        # algorithmic bytes per launch / kernel time against the HBM peak.  The scene is cache-resident, so that figure is
+        # served by L1 / scalar cache / L2 and exceeds the HBM peak: a work rate, not a bandwidth.
         src, ctr = profile_counters(args.workload, kernel_ms) if world == 1 else ({"profile": None, "matches_this_kernel": False}, None)
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": ctr["traffic"] if ctr else None, "algorithmic_bytes_per_launch": alg,
-                    "bound_actual": "wave latency at 4 waves/SIMD: neither HBM (3 % of peak, the scene stays in cache) nor the vector pipe (valu_pipe_frac) "
-                                    "is full; a wave issues ~38 % of its life (wave_issuing_frac), waits at s_waitcnt ~27 % (wave_waitcnt_frac); "
-                                    "valu_busy is the waves' VALU issue time, 4 cycles per instruction, not pipe occupancy (DESIGN.md section 4)",
+        sec = kernel_ms * 1e-3
+        slots = ctr and ctr.get("issue_slots_per_launch")
+        issue_achieved = slots / sec / 1e9 if slots else None
+        cadence = None
+        if ctr and ctr.get("insts_per_launch"):
+            per_simd_cycle = ctr["insts_per_launch"] / sec / 1e9 / ISSUE_PEAK_GSLOTS   # instructions per SIMD-cycle at the 2.4 GHz the peak assumes
+            possible = ctr["waves_per_simd"] / WAVE_CADENCE_CYCLES
+            cadence = {"cycles_between_instructions_of_a_wave": WAVE_CADENCE_CYCLES, "waves_per_simd": ctr["waves_per_simd"],
+                       "insts_per_simd_cycle_possible": possible, "insts_per_simd_cycle_achieved": per_simd_cycle, "frac": per_simd_cycle / possible}
+        roofline = {"bound": "issue", "achieved": issue_achieved, "peak": ISSUE_PEAK_GSLOTS, "unit": "G issue-slots/s (SIMD-cycles of issue per second)",
+                    "frac": issue_achieved / ISSUE_PEAK_GSLOTS if issue_achieved else None,
+                    "traffic": ctr["traffic"] if ctr else None,
+                    "model": "issue slots = instructions of one launch (rocprofv3 SQ_INSTS_* of this kernel source, profiles/) at 1 SIMD-cycle each, fp64 add/mul/fma 1.93, "
+                             "fp64 rcp/rsq/sqrt 6.0 (tools/micro/issue_rates.hip, profiles/r04/micro/issue_rates.txt) / this run's mean HIP-event duration; "
+                             "peak = 1024 SIMDs x 2.4 GHz, one instruction per SIMD-cycle with all 8 wave slots occupied",
+                    "insts_per_launch": ctr and ctr.get("insts_per_launch"), "issue_slots_per_launch": slots,
+                    "occupancy_limited_issue": cadence,
+                    "bound_actual": "instruction issue at the occupancy the fp64 state allows: the kernel holds 128 VGPRs = 4 waves/SIMD, a wave that shares its SIMD "
+                                    "issues one instruction per ~8.3 cycles, so 4 waves can issue 0.48 instructions per SIMD-cycle and the kernel issues "
+                                    "occupancy_limited_issue.frac of that (the rest: waits on scalar-cache / LDS / L2 round trips); HBM (3 % of peak, the "
+                                    "scene stays in cache) and the vector pipe (valu_pipe_frac) are far from full (DESIGN.md section 4)",
+                    "scalar_dcache_hit_rate": ctr and ctr.get("scalar_dcache_hit_rate"), "scalar_icache_hit_rate": ctr and ctr.get("scalar_icache_hit_rate"),
+                    # SURVEY.md 8(d)'s contract figures: algorithmic bytes / kernel time against the HBM peak (> 1: the bytes are served by the caches)
+                    "hbm_contract": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                     "algorithmic_bytes_per_launch": alg, "note": "a work rate, not a bandwidth: the 13 MB scene is L2 / scalar-cache resident"},
                     "hbm_traffic_frac": ctr and ctr["hbm_traffic_frac"], "hbm_read_frac": ctr and ctr["hbm_read_frac"],
                     "hbm_write_bytes": ctr and ctr["hbm_write_bytes"], "l2_hit_rate": ctr and ctr["l2_hit_rate"],
                     "valu_busy": ctr and ctr["valu_busy"], "valu_lane_util": ctr and ctr["valu_lane_util"],

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -31,6 +32,7 @@ hipError_t launch_static_costs_exact(hipStream_t stream, const DScene &sc, const
 hipError_t launch_order_tiles_exact(hipStream_t stream, float *cost, int n, int *order, unsigned *aux, unsigned long long *next_ticket, int ticket_slots);
 hipError_t launch_trace_exact(int variant, int grid, size_t lds_bytes, hipStream_t stream, const DScene &sc, const DCamera &cam,
                               const DParams &prm, void *out, unsigned long long *counters, unsigned long long *ticket, double *frames);
+hipError_t launch_warmup_exact(hipStream_t stream);
 int occupancy_trace_fast(int variant, size_t lds_bytes);
 int occupancy_trace_exact(int variant, size_t lds_bytes);
 int stack_entry_bytes_fast(int variant);
@@ -112,12 +114,39 @@ extern "C" int rayhs_device_count(void) {
 }
 
 extern "C" int rayhs_device_prepare(int device) {
-    int ndev = rayhs_device_count();
+    using clk = std::chrono::steady_clock;
+    const bool verbose = std::getenv("RAYHS_DEBUG_TIMING") != nullptr;  // development: where a process's HIP start-up goes
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const clk::time_point t0 = clk::now();
+    int ndev = rayhs_device_count();                 // the first HIP call of the process: hipInit
+    const clk::time_point t1 = clk::now();
     if (ndev <= 0) return set_error(RAYHS_ERR_NO_DEVICE, "no HIP device available (librayhs_hip has no CPU fallback)");
     if (device < 0 || device >= ndev) return set_error(RAYHS_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFree(nullptr));                       // creates the context
-    (void)occupancy_trace_exact(0, 40 * 1024);       // resolves the kernel: loads the code object onto this device
+    // What a process pays once besides hipInit (measured, profiles/r04/cli_startup.md): ~20 ms at its first host -> device copy
+    // (the runtime's copy path), ~8 ms at the first copy back, ~20 ms at its first launch.  The occupancy query below resolves
+    // this library's kernels in < 1 ms: the 600 KB code object is NOT what start-up waits for.  Paying the copy / launch costs
+    // here instead (RAYHS_WARM_COPY / RAYHS_WARM_LAUNCH) moved them without shortening a one-shot run, so they stay opt-in.
+    const clk::time_point t2 = clk::now();
+    double ms_copy1 = 0, ms_copy2 = 0;
+    if (std::getenv("RAYHS_WARM_COPY")) {   // (opt-in: measured, it moves the cost without shortening the run -- profiles/r04/cli_startup.md)
+        void *q = nullptr; char buf[64] = {0};
+        if (hipMalloc(&q, 64) == hipSuccess) {
+            (void)hipMemcpy(q, buf, 64, hipMemcpyHostToDevice);
+            const clk::time_point c1 = clk::now();
+            (void)hipMemcpy(buf, q, 64, hipMemcpyDeviceToHost);
+            (void)hipFree(q);
+            ms_copy1 = ms(t2, c1); ms_copy2 = ms(c1, clk::now());
+        }
+    }
+    const clk::time_point t3 = clk::now();
+    (void)occupancy_trace_exact(0, 40 * 1024);
+    if (std::getenv("RAYHS_WARM_LAUNCH")) { (void)launch_warmup_exact(nullptr); (void)hipStreamSynchronize(nullptr); }  // (opt-in, as above)
+    const clk::time_point t4 = clk::now();
+    if (verbose)
+        std::fprintf(stderr, "rayhs_device_prepare(%d): hipInit (first HIP call) %.1f ms, context %.1f ms, first 64-byte copy to the device %.1f ms and back %.1f ms, "
+                             "first launch (queue + code object of the exact kernels) %.1f ms\n", device, ms(t0, t1), ms(t1, t2), ms_copy1, ms_copy2, ms(t3, t4));
     return RAYHS_OK;
 }
 
@@ -194,14 +223,20 @@ static int check_desc(const rayhs_scene_desc *d, int &tree_depth) {
     return RAYHS_OK;
 }
 
+static thread_local double g_ms_malloc = 0, g_ms_copy = 0;  // development (RAYHS_DEBUG_TIMING)
 template <class T>
 static int upload(rayhs_scene *s, const std::vector<T> &v, const T **out) {
+    using clk = std::chrono::steady_clock;
     *out = nullptr;
     size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
     void *p = nullptr;
+    const clk::time_point t0 = clk::now();
     HIP_TRY(hipMalloc(&p, bytes));
+    const clk::time_point t1 = clk::now();
     s->allocs.push_back(p);
     if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    g_ms_malloc += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    g_ms_copy += std::chrono::duration<double, std::milli>(clk::now() - t1).count();
     *out = (const T *)p;
     return RAYHS_OK;
 }
@@ -439,9 +474,13 @@ static int upload_scene(const PackedScene &pk, int device, rayhs_scene **out) {
     int ndev = rayhs_device_count();
     if (ndev <= 0) return set_error(RAYHS_ERR_NO_DEVICE, "no HIP device available (librayhs_hip has no CPU fallback)");
     if (device < 0 || device >= ndev) return set_error(RAYHS_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
+    using clk = std::chrono::steady_clock;
+    const clk::time_point tu0 = clk::now();
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const clk::time_point tu1 = clk::now();
+    g_ms_malloc = g_ms_copy = 0;
     int rc;
     rayhs_scene *s = new rayhs_scene();
     s->device = device;
@@ -476,6 +515,9 @@ static int upload_scene(const PackedScene &pk, int device, rayhs_scene **out) {
     if (hipMalloc(&p, sizeof(unsigned long long) * CNT_SLOTS_DEV) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(counters) failed"));
     s->counters = (unsigned long long *)p;
     *out = s;
+    if (std::getenv("RAYHS_DEBUG_TIMING"))
+        std::fprintf(stderr, "upload_scene: wait for the runtime + device properties %.1f ms, 12 x hipMalloc %.1f ms, 12 x hipMemcpy %.1f ms, all %.1f ms\n",
+                     std::chrono::duration<double, std::milli>(tu1 - tu0).count(), g_ms_malloc, g_ms_copy, std::chrono::duration<double, std::milli>(clk::now() - tu0).count());
     return RAYHS_OK;
 }
 
@@ -483,10 +525,17 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
     if (!out) return set_error(RAYHS_ERR_INVALID, "out is NULL");
     *out = nullptr;
     // (validation and packing come first: a bad description is reported as such even where no device exists)
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t0 = clk::now();
     PackedScene pk;
     int rc = pack_scene(desc, pk);
     if (rc) return rc;
-    return upload_scene(pk, device, out);
+    const clk::time_point t1 = clk::now();
+    rc = upload_scene(pk, device, out);
+    if (std::getenv("RAYHS_DEBUG_TIMING"))  // development: (the upload waits for rayhs_device_prepare when that runs on another thread)
+        std::fprintf(stderr, "rayhs_scene_create: validate + flatten + BVH %.1f ms, device allocation + upload %.1f ms\n",
+                     std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(clk::now() - t1).count());
+    return rc;
 }
 
 extern "C" void rayhs_scene_destroy(rayhs_scene *s) {
@@ -587,12 +636,13 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     // 1 counting, 2 exhaustive + counting (the reference's tree)
     variant = (p->flags & RAYHS_FLAG_EXHAUSTIVE) ? 2 : (p->flags & RAYHS_FLAG_COUNT) ? 1 : (s->d.n_fnodes < 65536 && s->d.n_nodes < 65536 ? 0 : 3);
     dp.stack_cap = std::max(std::max(s->tree_depth, s->fast_depth) + 2, 4);  // either tree may be walked (trace_kernel.hip)
+    if (const char *e = std::getenv("RAYHS_STACK_CAP")) dp.stack_cap = std::max(4, std::atoi(e));  // development knob (UNSAFE below the tree depth)
     const int entry = exact ? stack_entry_bytes_exact(variant) : stack_entry_bytes_fast(variant);
     // LDS per workgroup: context slots + stack.  160 KiB per CU / 4 workgroups = 40 KiB each; if the stack
     // leaves room, three more context slots keep the light term in LDS instead of the global workspace.
     const size_t stack_bytes = (size_t)dp.stack_cap * TRACE_BLOCK * (size_t)entry;
     dp.ctx_slots = CTX_SLOTS;
-    if ((size_t)(CTX_SLOTS + 3) * TRACE_BLOCK * sizeof(double) + stack_bytes <= 40 * 1024) dp.ctx_slots = CTX_SLOTS + 3;
+    if ((size_t)(CTX_SLOTS + 3) * TRACE_BLOCK * sizeof(double) + stack_bytes <= 40 * 1024 && !std::getenv("RAYHS_TERM_IN_WORKSPACE")) dp.ctx_slots = CTX_SLOTS + 3;
     lds = (size_t)dp.ctx_slots * TRACE_BLOCK * sizeof(double) + stack_bytes;
     if (lds > 160 * 1024) return set_error(RAYHS_ERR_UNSUPPORTED, "tree depth %d needs %zu B of LDS per workgroup (limit 160 KiB)", dp.stack_cap - 2, lds);
     // persistent grid: as many workgroups as the chip keeps resident
@@ -795,6 +845,8 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
     if (rows < 0) return rows;
     if (p->width <= 0) return set_error(RAYHS_ERR_INVALID, "bad width");
     HIP_TRY(hipSetDevice(s->device));
+    using clk = std::chrono::steady_clock;
+    const clk::time_point tt0 = clk::now();
     size_t esz = p->out_format == RAYHS_OUT_F64 ? 8 : p->out_format == RAYHS_OUT_F32 ? 4 : 2;
     size_t bytes = (size_t)rows * (size_t)p->width * 3 * esz;
     // the device frame and the two timing events live with the handle (grow-only): repeated calls allocate nothing
@@ -808,10 +860,28 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
     if (!s->host_e1) HIP_TRY(hipEventCreate(&s->host_e1));
     const bool count = (p->flags & RAYHS_FLAG_COUNT) != 0;
     if (count) HIP_TRY(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * CNT_SLOTS_DEV, nullptr));
+    if (std::getenv("RAYHS_DEBUG_TIMING") && std::getenv("RAYHS_DEBUG_SYNC_FIRST")) {  // development: is anything still pending from the uploads?
+        const clk::time_point q0 = clk::now();
+        (void)hipDeviceSynchronize();
+        std::fprintf(stderr, "rayhs_render: hipDeviceSynchronize before the launch took %.1f ms\n", std::chrono::duration<double, std::milli>(clk::now() - q0).count());
+    }
+    const clk::time_point tt1 = clk::now();
     int rc = launch(s, cam, p, s->host_out_dev, nullptr, count ? (uint64_t *)s->counters : nullptr, s->host_e0, s->host_e1);
     if (rc) return rc;
+    const clk::time_point tt2 = clk::now();
+    clk::time_point tt3 = tt2, tt4 = tt2;
+    if (std::getenv("RAYHS_DEBUG_TIMING")) {  // development: when the trace kernel starts and ends, seen from the host
+        (void)hipEventSynchronize(s->host_e0); tt3 = clk::now();
+        (void)hipEventSynchronize(s->host_e1); tt4 = clk::now();
+    }
     // the copy is ordered behind the kernels on the NULL stream and blocks the host until the frame is there
     if (bytes) HIP_TRY(hipMemcpy(out_host, s->host_out_dev, bytes, hipMemcpyDeviceToHost));
+    if (std::getenv("RAYHS_DEBUG_TIMING")) {
+        auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "rayhs_render: output buffer + events %.1f ms, enqueue (workspace, order buffers, launches) %.1f ms, until the trace kernel starts %.1f ms, "
+                             "until it ends %.1f ms, copy of %zu bytes to the host %.1f ms\n",
+                     ms(tt0, tt1), ms(tt1, tt2), ms(tt2, tt3), ms(tt3, tt4), bytes, ms(tt4, clk::now()));
+    }
     HIP_TRY(hipStreamSynchronize(nullptr));
     if (stats) {
         std::memset(stats, 0, sizeof *stats);

@@ -46,7 +46,11 @@ static int max_leaf() {  // development knob: RAYHS_BVH_LEAF=1..7; 2..6 measure 
     return v;
 }
 #define kMaxLeaf (max_leaf())
-constexpr int kDepthLimit = 28;  // SAH splits only while depth + ceil(log2 n) stays below this; median splits
+static int depth_limit() {  // development knob: RAYHS_BVH_DEPTH_LIMIT (default 28)
+    static int v = [] { const char *e = std::getenv("RAYHS_BVH_DEPTH_LIMIT"); int n = e ? std::atoi(e) : 28; return n < 4 ? 4 : n > 28 ? 28 : n; }();
+    return v;
+}
+#define kDepthLimit (depth_limit())  // SAH splits only while depth + ceil(log2 n) stays below this; median splits
                                  // (which halve n) are used otherwise, so inner nodes never sit deeper than this
 
 struct Builder {

@@ -1657,8 +1657,16 @@ RAYHS_CAT(rayhs_scatter_stripes, RAYHS_KERNEL_SUFFIX)(const char *src, char *dst
     }
 }
 
+// rayhs_device_prepare launches this once: the first launch of a process pays for the compute queue and for putting this
+// translation unit's code object on the device (~20 ms), which a one-shot `rayhs -oX scene.json` can spend while it still parses
+extern "C" __global__ void RAYHS_CAT(rayhs_warmup, RAYHS_KERNEL_SUFFIX)() {}
+
 // Host-side launcher of this translation unit's kernels (called from abi.cpp).
 namespace rayhs {
+hipError_t RAYHS_CAT(launch_warmup, RAYHS_KERNEL_SUFFIX)(hipStream_t stream) {
+    hipLaunchKernelGGL(RAYHS_CAT(rayhs_warmup, RAYHS_KERNEL_SUFFIX), dim3(1), dim3(64), 0, stream);
+    return hipGetLastError();
+}
 static const void *RAYHS_CAT(kernel_ptr, RAYHS_KERNEL_SUFFIX)(int variant) {
     switch (variant) {
     case 0: return (const void *)RAYHS_CAT(rayhs_trace, RAYHS_KERNEL_SUFFIX);

@@ -5,7 +5,7 @@
 # one stream: the --stats rows of every kernel are then its real duration), and four PMC passes (counters in their own
 # runs, no other trace domain -- see MI355X_MICROARCH.md, HBM/rocprofv3 section).
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 wl=${2:-dragon}
 out=gpurun_out
 pre=$out/${tag}_${wl}
@@ -24,5 +24,9 @@ pmc sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 pmc sq2 SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_FLAT GRBM_GUI_ACTIVE || exit 6
 # instruction mix: what the vector pipe is really asked for (fp64 arithmetic runs at half rate, transcendentals at an eighth) and the branches
 pmc mix SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES || exit 7
+# scalar data cache (the packet walk fetches its nodes and triangles through it) and instruction cache; optional passes: a
+# counter this rocprofv3 build does not know must not lose the rest of the profile
+pmc sqc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE || echo "pmc pass sqc failed"
+pmc sqc2 SQC_DCACHE_REQ_READ_1 SQC_DCACHE_REQ_READ_2 SQC_DCACHE_REQ_READ_4 SQC_DCACHE_REQ_READ_8 SQC_DCACHE_REQ_READ_16 SQC_TC_DATA_READ_REQ SQC_TC_INST_REQ SQC_TC_STALL || echo "pmc pass sqc2 failed"
 RAYHS_DEBUG_COUNTERS=1 python3 tools/kbench.py $wl 1 2>&1 | grep "rayhs launch" | tail -1 > ${pre}_launch.txt
 cat ${pre}_bench.json

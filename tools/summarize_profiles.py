@@ -11,7 +11,7 @@ import collections, csv, glob, json, os, re, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 wl = sys.argv[2] if len(sys.argv) > 2 else "dragon"
 src, pre = "gpurun_out", f"gpurun_out/{tag}_{wl}"
 dst = os.path.join("profiles", tag, wl)
@@ -45,6 +45,8 @@ for f in newest(f"{pre}_trace/*/*_kernel_trace.csv"):
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows[len(rows) - after - steps:len(rows) - after]]
         out["timed_launches"] = {"kernel": rows[-1]["Kernel_Name"], "launches": steps, "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d),
                                  "bench_events_avg_ms": tb.get("kernel_ms_rank0"), "first_frame_ms": tb.get("first_frame_ms")}
+# SIMD-cycles one instruction costs at full occupancy (profiles/r04/micro/issue_rates.txt, column w32)
+ISSUE_COST = {"any": 1.0, "fp64": 1.93, "fp64_trans": 6.0}
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in [g for d in glob.glob(f"{pre}_pmc_*") for g in newest(f"{d}/*/*_counter_collection.csv")]:
     for r in csv.DictReader(open(f)):
@@ -82,6 +84,25 @@ for k, d in out["pmc_mean_per_launch"].items():
         d["fp64_flops_per_launch"] = 64.0 * (f64[0] + f64[1] + 2 * f64[2])   # wave-level instructions x 64 lanes (an upper bound: idle lanes count)
     if "SQ_INSTS_BRANCH" in d and "SQ_INSTS_VALU" in d:
         d["branches_per_valu"] = d["SQ_INSTS_BRANCH"] / d["SQ_INSTS_VALU"]
+    # THE ROOF THAT BINDS: instruction issue.  tools/micro/issue_rates.hip (profiles/r04/micro/issue_rates.txt) measures what a
+    # SIMD of gfx950 issues: with all 8 wave slots occupied, one instruction of ANY class per ~1.0 cycle (scalar, fp32 /
+    # integer vector, branch: 0.88-1.12 SIMD-cycles each, alone or mixed), one fp64 add / mul / fma per 1.93, one fp64
+    # rcp / rsq / sqrt per 6.0.  issue_slots = instructions priced at those costs; the SIMD-cycles of the launch are the peak.
+    # A single wave that shares its SIMD issues one instruction per ~8.3 cycles in mixed scalar / vector code whatever
+    # the number of co-resident waves (2..8): `wave_cadence_*` prices the launch against what its OWN occupancy can issue.
+    classes = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")
+    if all(c in d for c in classes) and all(v is not None for v in f64) and "SQ_INSTS_VALU_TRANS_F64" in d and "GRBM_GUI_ACTIVE" in d:
+        insts = sum(d[c] for c in classes)     # (SQ_INSTS_FLAT counts the same global_* instructions as VMEM_RD + VMEM_WR)
+        arith, trans = sum(f64), d["SQ_INSTS_VALU_TRANS_F64"]
+        simd_cycles = d["GRBM_GUI_ACTIVE"] / 8 * 256 * 4
+        d["insts_per_launch"] = insts
+        d["issue_slots_per_launch"] = (insts - arith - trans) * ISSUE_COST["any"] + arith * ISSUE_COST["fp64"] + trans * ISSUE_COST["fp64_trans"]
+        d["simd_cycles_per_launch"] = simd_cycles
+        d["issue_frac"] = d["issue_slots_per_launch"] / simd_cycles
+        d["insts_per_simd_cycle"] = insts / simd_cycles
+    for cache in ("DCACHE", "ICACHE"):
+        if f"SQC_{cache}_REQ" in d and f"SQC_{cache}_MISSES" in d and d[f"SQC_{cache}_REQ"] > 0:
+            d[f"scalar_{cache.lower()}_hit_rate"] = 1.0 - (d[f"SQC_{cache}_MISSES"] + d.get(f"SQC_{cache}_MISSES_DUPLICATE", 0.0)) / d[f"SQC_{cache}_REQ"]
 # dispatch: the code object's own metadata + the launch the library reports
 disp = {}
 try:
@@ -98,6 +119,7 @@ if os.path.exists(pre + "_launch.txt"):
         disp["launch"] = {"variant": int(m.group(1)), "lds_bytes_per_workgroup": int(m.group(2)), "workgroups_per_cu": int(m.group(3)), "stack_cap": int(m.group(4)),
                           "workgroup_size": 256, "waves_per_simd": int(m.group(3))}
 out["dispatch"] = disp
+out["issue_cost_simd_cycles"] = ISSUE_COST
 for name, to in ((f"{tag}_{wl}_bench.json", "bench.json"), (f"{tag}_{wl}_trace_bench.json", "trace_bench.json")):
     p = os.path.join(src, name)
     if os.path.exists(p):
