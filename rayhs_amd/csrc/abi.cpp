@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <thread>
 #include <vector>
@@ -349,7 +350,7 @@ static int pack_scene(const rayhs_scene_desc *desc, PackedScene &pk) {
         auto fbox32 = [&](const double *lo, const double *hi, float *b) {
             for (int c = 0; c < 3; c++) {
                 if (lo[c] <= hi[c]) { b[2 * c] = round_down_f32((lo[c] - ctr[c]) - infl); b[2 * c + 1] = round_up_f32((hi[c] - ctr[c]) + infl); }
-                else { b[2 * c] = 0; b[2 * c + 1] = 0; }  // absent child: its reference is FNODE_NONE, the box is never used
+                else { b[2 * c] = b[2 * c + 1] = std::numeric_limits<float>::quiet_NaN(); }  // absent child (reference FNODE_NONE): a NaN box fails every slab test, so the walks need no test of their own
             }
         };
         // inner references index the global node array; leaf references ~((first << 3) | count) index the

@@ -28,7 +28,7 @@ static constexpr int32_t DNODE_LEAF = (int32_t)0x80000000;
 // multiply-add per axis,  t = plane * (1/d) + (-o/d),  with no decode step.  (32-byte nodes with 16-bit grid
 // coordinates were 2 % slower once the waves were coherent: 12 conversions per visit cost more than the bytes.)
 // Child reference: >= 0 inner node, < 0 leaf ~((first << 3) | count) into the BVH-ordered triangle
-// array, INT32_MIN = no child.
+// array, INT32_MIN = no child (its box is NaN: it fails every slab test, so the walks never look at the reference).
 struct alignas(16) FNode {
     float b0[6], b1[6];
     int32_t c0, c1;

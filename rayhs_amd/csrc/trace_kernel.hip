@@ -319,10 +319,10 @@ struct Tracer {
 
     // closest-hit record
     // (the barycentrics of a winning triangle are not kept: the shading section re-runs the test on that one triangle,
-    // which yields the same doubles; the tie ranks live only while their mesh is walked)
+    // which yields the same doubles; its place in the reference's order is not kept either: an exact tie between two
+    // triangles of one mesh -- a ray through a shared edge or vertex -- reads it back from the triangle's record)
     double bt;
     int bobj, btri;
-    int bleaf, brank;  // reference leaf / rank of the best triangle of the mesh being walked (-1: none yet)
     int bprim;  // winning plane index i, or sphere index as -(i + 2); -1 for a triangle / miss
     bool bref;  // btri indexes the reference-order arrays (hit found by the reference tree), else the BVH-order ones
     bool occ;   // shadow query: an occluder was found
@@ -341,7 +341,7 @@ struct Tracer {
     };
 
     __device__ Tracer(stack_ptr st, Counters &c) : stack(st), cnt(c) {
-        bt = 0; bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; occ = false; armed = false;
+        bt = 0; bobj = -1; btri = -1; bprim = -1; bref = EXH; occ = false; armed = false;
     }
 
     // ---- analytic primitives (src/Geometry.hs:68-96) ----
@@ -360,8 +360,12 @@ struct Tracer {
             num = dot(pn, sub(pp, r.o));
         }
     }
+    // A SUPERSET of the lanes where num / den > 0 is all the caller needs (it only decides whether the wave divides at all;
+    // the division's own result is then tested exactly): operands of equal sign.  One integer instruction on the high words
+    // and one compare, instead of four fp64 compares and three mask operations; zeros and NaNs of equal sign bit pass and
+    // are rejected by the exact test.
     static __device__ __forceinline__ unsigned long long quotient_may_be_positive(double num, double den) {  // wave mask
-        return (__ballot(num > 0) & __ballot(den > 0)) | (__ballot(num < 0) & __ballot(den < 0));
+        return __ballot((__double2hiint(num) ^ __double2hiint(den)) >= 0);
     }
     // Sphere (src/Geometry.hs:78-85): the discriminant first; the roots (a square root and two divisions) only when
     // some lane of the wave has delta >= 0.
@@ -437,10 +441,13 @@ struct Tracer {
         bool take = t < bt;
         if (t == bt) {
             if (obj != bobj) take = obj < bobj;
-            else if (leaf_first != bleaf) take = leaf_first > bleaf;
-            else take = rank < brank;
+            else {  // the best so far is a triangle of the same mesh (an object is one primitive or one mesh)
+                const DTri &best = rec(bref ? SC.tris : SC.ftris, btri);
+                const int bleaf = best.leaf_first, brank = best.rank;
+                take = leaf_first != bleaf ? leaf_first > bleaf : rank < brank;
+            }
         }
-        if (take) { bt = t; bobj = obj; btri = tri; bleaf = leaf_first; brank = rank; bprim = -1; }
+        if (take) { bt = t; bobj = obj; btri = tri; bprim = -1; }
         return take;
     }
 
@@ -488,7 +495,7 @@ struct Tracer {
     __device__ void begin(int kind, const Ray &r, bool point_light, double light_d2) {
         const bool active = kind != Q_NONE;
         const bool shadow = kind == Q_SHADOW;
-        if (active) { bt = __builtin_inf(); bobj = -1; btri = -1; bleaf = -1; brank = -1; bprim = -1; bref = EXH; }
+        if (active) { bt = __builtin_inf(); bobj = -1; btri = -1; bprim = -1; bref = EXH; }
         armed = false;
 
         // ---- planes and spheres: wave-uniform loops, scene constants via scalar loads.  Every per-lane yes/no of
@@ -503,6 +510,7 @@ struct Tracer {
         const mask_t m_point = __ballot(active && shadow && point_light);  // shadow queries towards a point light
         mask_t m_occ = 0;  // lanes whose shadow query has found an occluder
         const double a = dot(r.d, r.d);
+        const double a_margin = a * (1.0 - 1e-4);  // (the margin of the "beyond the light" shortcut below, folded in once per query)
         const double o_max = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z));
         const double o_guard = (o_max * o_max) * 1e-18;
         const int n_planes = SC.n_planes, n_spheres = SC.n_spheres, n_meshes = SC.n_meshes;
@@ -532,8 +540,8 @@ struct Tracer {
             mask_t m_beyond = 0;
             if (m_point != 0ull) {
                 const double q = num * __builtin_amdgcn_rcp(den);
-                const double s_far = (q * q) * a;
-                m_beyond = m_point & __ballot(s_far * (1.0 - 1e-4) > light_d2) & __ballot(s_far > o_guard);
+                const double q2 = q * q, s_far = q2 * a;
+                m_beyond = m_point & __ballot(q2 * a_margin > light_d2) & __ballot(s_far > o_guard);
             }
             // (every ballot is of ONE comparison: the compare then writes the mask itself; a ballot of `a && b` goes through
             // a 0/1 vector register)
@@ -650,8 +658,8 @@ struct Tracer {
     // (wave-uniform visit: the fields are scalar loads and the child references stay in SGPRs).
     template <class ND> __device__ __forceinline__ void visit(Walk &w, const ND &nd, float limf) {
         float tn0, tn1;
-        const bool h0 = pbox(nd.b0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0) && nd.c0 != FNODE_NONE;
-        const bool h1 = pbox(nd.b1, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn1) && nd.c1 != FNODE_NONE;
+        const bool h0 = pbox(nd.b0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0);  // (an absent child's box is NaN: never met)
+        const bool h1 = pbox(nd.b1, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn1);
         if (COUNT) cnt.c[CNT_NODES] += (nd.c0 != FNODE_NONE) + (nd.c1 != FNODE_NONE);
         const bool near0 = tn0 <= tn1;
         const bool l0 = h0 && nd.c0 < 0, l1 = h1 && nd.c1 < 0;    // hit leaves
@@ -782,16 +790,23 @@ struct Tracer {
                     float tn0, tn1;
                     const unsigned long long b0 = pbox_mask(nd.b0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0);
                     const unsigned long long b1 = pbox_mask(nd.b1, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn1);
-                    const unsigned long long m0 = c0 != FNODE_NONE ? (b0 & m_live) : 0ull, m1 = c1 != FNODE_NONE ? (b1 & m_live) : 0ull;
+                    const unsigned long long m0 = b0 & m_live, m1 = b1 & m_live;  // (an absent child's box is NaN: no lane meets it)
                     if (COUNT) cnt.c[CNT_NODES] += __builtin_amdgcn_inverse_ballot_w64(m_live) ? (c0 != FNODE_NONE) + (c1 != FNODE_NONE) : 0;
-                    // the child that more of the lanes that hit something would take first
+                    // the child that more of the lanes that hit something would take first: (ca, ma) before (cb, mb).  The choice is
+                    // made by the scalar unit (left to the compiler the comparison of the two population counts went through a
+                    // vector compare and back)
                     const unsigned long long pref0 = m0 & (~m1 | __ballot(tn0 <= tn1));
-                    const bool first0 = (int)__popcll(pref0) >= (int)__popcll((m0 | m1) & ~pref0);
+                    const int n_pref0 = (int)__popcll(pref0), n_pref1 = (int)__popcll((m0 | m1) & ~pref0);
+                    int ca, cb;
+                    unsigned long long ma, mb;
+                    asm("s_cmp_ge_i32 %8, %9\n\ts_cselect_b32 %0, %4, %5\n\ts_cselect_b32 %1, %5, %4\n\ts_cselect_b64 %2, %6, %7\n\ts_cselect_b64 %3, %7, %6"
+                        : "=&s"(ca), "=&s"(cb), "=&s"(ma), "=&s"(mb) : "s"(c0), "s"(c1), "s"(m0), "s"(m1), "s"(n_pref0), "s"(n_pref1) : "scc");
                     int next = FNODE_NONE;
+                    // (a visit specialised for "both children are inner nodes" -- no leaf code, three branches instead of ten -- was
+                    // measured and dropped: +4 % on the dragon frame, profiles/r04/experiments/visit_variants.log)
                     for (int side = 0; side < 2; side++) {
-                        const bool zero = (side == 0) == first0;
-                        const int c = zero ? c0 : c1;
-                        const unsigned long long m_side = zero ? m0 : m1;
+                        const int c = side == 0 ? ca : cb;
+                        const unsigned long long m_side = side == 0 ? ma : mb;
                         if (m_side == 0ull) continue;
                         if (c >= 0) {  // inner child: walk it next, or after the first one
                             if (next == FNODE_NONE) next = c;
@@ -825,11 +840,17 @@ struct Tracer {
                                 // offer(): smaller t; at an exact tie the first object, the right-most leaf, the first triangle of a leaf
                                 unsigned long long m_take = __ballot(t < bt);
                                 const unsigned long long m_eq = m_cl & __ballot(t == bt);
-                                if (m_eq != 0ull)
+                                if (m_eq != 0ull) {  // (rare: a ray through an edge or a vertex two triangles share)
+                                    int bleaf = -1, brank = -1;
+                                    if (__builtin_amdgcn_inverse_ballot_w64(m_eq) && obj == bobj) {
+                                        const DTri &best = rec(bref ? SC.tris : SC.ftris, btri);
+                                        bleaf = best.leaf_first; brank = best.rank;
+                                    }
                                     m_take |= m_eq & (__ballot(obj < bobj) | (__ballot(obj == bobj) & (__ballot(tr.leaf_first > bleaf) | (__ballot(tr.leaf_first == bleaf) & __ballot(tr.rank < brank)))));
+                                }
                                 const bool take = __builtin_amdgcn_inverse_ballot_w64(m_take & m_cl);
-                                bt = take ? t : bt; bobj = take ? obj : bobj; btri = take ? k : btri; bleaf = take ? tr.leaf_first : bleaf;
-                                brank = take ? tr.rank : brank; bprim = take ? -1 : bprim; bref = take ? false : bref;
+                                bt = take ? t : bt; bobj = take ? obj : bobj; btri = take ? k : btri;
+                                bprim = take ? -1 : bprim; bref = take ? false : bref;
                                 limf = take ? f32_up(bt - (double)w.t_enter) : limf;
                             }
                         }
@@ -1116,7 +1137,27 @@ static __device__ __forceinline__ void trace_body() {
                 if (tr.bobj < 0) { cx_store3(cx, CX_A, mk(0, 0, 0)); step = A_RETURN; }
                 else {
                     const DObject *const objects = SC.objects;
-                    const DObjectHot ob = *(const DObjectHot *)&rec(objects, tr.bobj);  // by value: one batch of loads, not field by field per branch
+                    // (what every material reads of the object; ior of a Transparent one is fetched where it is used)
+                    struct { int mat_kind, cmap_kind; double c1[3]; } ob;
+                    { const DObject &q = rec(objects, tr.bobj); ob.mat_kind = q.mat_kind; ob.cmap_kind = q.cmap_kind; ob.c1[0] = q.c1[0]; ob.c1[1] = q.c1[1]; ob.c1[2] = q.c1[2]; }
+                    // Everything a triangle hit reads -- the object record above, the triangle, its normals -- is requested in ONE
+                    // batch, in front of the first store of the section (a load cannot be moved above a store that might alias it).
+                    // Left to itself the section made four DEPENDENT vector-memory round trips: the two array bases chosen per
+                    // lane (reference order or BVH order: a per-lane pointer, loaded per lane), the triangle, then the normals.  Hits
+                    // found by the reference tree (rays with a zero direction component) are rare: the wave asks once whether it holds any.
+                    const bool is_tri = tr.btri >= 0;
+                    const bool some_ref = EXH || __ballot(is_tri && tr.bref) != 0ull;
+                    const DTri *const t_arr = !some_ref ? SC.ftris : (tr.bref ? SC.tris : SC.ftris);
+                    const DTriAttr *const a_arr = !some_ref ? SC.fattrs : (tr.bref ? SC.attrs : SC.fattrs);
+                    struct { double p0[3], e1[3], e2[3]; } h_tri;
+                    V3 h_n0 = mk(0, 0, 0), h_n1 = h_n0, h_n2 = h_n0;
+                    if (is_tri) {
+                        const DTri &q = rec(t_arr, tr.btri);
+                        for (int k = 0; k < 3; k++) { h_tri.p0[k] = q.p0[k]; h_tri.e1[k] = q.e1[k]; h_tri.e2[k] = q.e2[k]; }
+                        const DTriAttr &at = rec(a_arr, tr.btri);
+                        h_n0 = ld3(at.n0); h_n1 = ld3(at.n1); h_n2 = ld3(at.n2);
+                    }
+                    asm volatile("" ::: "memory");
                     if (COUNT) cnt.c[CNT_SHADED]++;
                     c_obj = tr.bobj;
                     const V3 c_p = add(ray.o, scl(tr.bt, ray.d));  // rayAt (src/Geometry.hs:27-29)
@@ -1125,14 +1166,14 @@ static __device__ __forceinline__ void trace_body() {
                     const int mat_kind = ob.mat_kind;
                     if (mat_kind == 0 || mat_kind == 2 || mat_kind == 4) PARK_V(ray.d);  // Mirror, Plastic, Transparent: the view direction is read again after the light loop
                     const bool need_uv = ((mat_kind == 1 || mat_kind == 2) && ob.cmap_kind != 0) || mat_kind == 6;
-                    if (tr.btri >= 0) {
-                        const DTriAttr &at = rec(tr.bref ? SC.attrs : SC.fattrs, tr.btri);
+                    if (is_tri) {
                         double u, v, t_again;  // the same test on the same ray and triangle: the same doubles as during the walk
-                        tr.tri_test(rec(tr.bref ? SC.tris : SC.ftris, tr.btri), ray, t_again, u, v);
+                        tr.tri_test(h_tri, ray, t_again, u, v);
                         const double w = 1 - u - v;
                         // barycentricInterp u n1 v n2 (1-u-v) n0 (src/Mesh.hs:53-57,73-74)
-                        c_n = add(add(scl(u, ld3(at.n1)), scl(v, ld3(at.n2))), scl(w, ld3(at.n0)));
+                        c_n = add(add(scl(u, h_n1), scl(v, h_n2)), scl(w, h_n0));
                         if (need_uv) {
+                            const DTriAttr &at = rec(a_arr, tr.btri);
                             hu = u * at.uv1[0] + v * at.uv2[0] + w * at.uv0[0];
                             hv = u * at.uv1[1] + v * at.uv2[1] + w * at.uv0[1];
                         }
@@ -1159,7 +1200,7 @@ static __device__ __forceinline__ void trace_body() {
                         cx_store3(cx, CX_A, ld3(rec(objects, tr.bobj).ce)); step = A_RETURN;
                     } else if (mat_kind == 4) {  // Transparent: try to transmit (src/RayHs.hs:136-143)
                         V3 refdir;
-                        if (fsp != PRM.max_depth && refract(ray.d, c_n, 1.0, ob.ior, refdir)) {
+                        if (fsp != PRM.max_depth && refract(ray.d, c_n, 1.0, rec(objects, tr.bobj).ior, refdir)) {
                             cx_store3(cx, CX_CD, refdir);  // keep refDir across the exit query
                             ray.o = add(c_p, scl(kEps, refdir)); ray.d = refdir;  // rayEps
                             if (COUNT) cnt.c[CNT_REFRACT_EXIT]++;
@@ -1181,11 +1222,16 @@ static __device__ __forceinline__ void trace_body() {
                     V3 outp = add(ray.o, scl(tr.bt, ray.d));
                     V3 outn;
                     if (tr.btri >= 0) {
-                        const DTriAttr &at = rec(tr.bref ? SC.attrs : SC.fattrs, tr.btri);
+                        // (one batch of loads, as in the hit section)
+                        const bool some_ref = EXH || __ballot(tr.bref) != 0ull;
+                        const DTri h_tri = rec(!some_ref ? SC.ftris : (tr.bref ? SC.tris : SC.ftris), tr.btri);
+                        const DTriAttr &at = rec(!some_ref ? SC.fattrs : (tr.bref ? SC.attrs : SC.fattrs), tr.btri);
+                        const V3 h_n0 = ld3(at.n0), h_n1 = ld3(at.n1), h_n2 = ld3(at.n2);
+                        asm volatile("" ::: "memory");
                         double u, v, t_again;
-                        tr.tri_test(rec(tr.bref ? SC.tris : SC.ftris, tr.btri), ray, t_again, u, v);
+                        tr.tri_test(h_tri, ray, t_again, u, v);
                         const double w = 1 - u - v;
-                        outn = add(add(scl(u, ld3(at.n1)), scl(v, ld3(at.n2))), scl(w, ld3(at.n0)));
+                        outn = add(add(scl(u, h_n1), scl(v, h_n2)), scl(w, h_n0));
                     } else if (tr.bprim >= 0) outn = ld3(rec(SC.planes, tr.bprim).n);
                     else outn = unit(sub(outp, ld3(rec(SC.spheres, -tr.bprim - 2).c)));
                     V3 outdir;
