@@ -291,18 +291,10 @@ constexpr bool kProfileTime = false;
 #define LOOP_TICK(slot) do { } while (0)
 #endif
 
-DEV float f32_up(double v) {  // smallest float >= v (v >= 0 here)
-    float f = (float)v;
-    if ((double)f < v) f = __uint_as_float(__float_as_uint(f) + 1u);
-    return f;
+DEV float f32_up(double v) {  // a float >= v, at most three ulps above it (v >= 0 here; only ever a culling limit: 0 stays 0, inf stays inf)
+    return (float)v * 1.00000024f;
 }
 
-#ifndef RAYHS_GROUP_COS
-#define RAYHS_GROUP_COS 0.9f
-#endif
-#ifndef RAYHS_GROUP_MAX
-#define RAYHS_GROUP_MAX 64
-#endif
 constexpr int kTileBits = 28, kTileMask = (1 << kTileBits) - 1;  // tile-order entry: tile index | issue-priority class << 28
 
 // ---- per-lane reads of scene records: uniform base (an SGPR pair) + 32-bit byte offset, so that the load uses the
@@ -475,9 +467,9 @@ struct Tracer {
         return __ballot(tf >= fmaxf(tn, 0.0f)) & __ballot(tn <= limf);
     }
 
-    // conservative fp32 slab test of the mesh bounds (root cull); t is relative to the given origin
-    __device__ __forceinline__ bool fbox(const float *lo, const float *hi, float ox, float oy, float oz, float ix, float iy, float iz,
-                                         float limf, float &tnear) {
+    // conservative fp32 slab test of the mesh bounds (root cull) as a wave mask; t is relative to the given origin
+    __device__ __forceinline__ unsigned long long fbox_mask(const float *lo, const float *hi, float ox, float oy, float oz, float ix, float iy, float iz,
+                                                            float limf, float &tnear) {
         float t1 = (lo[0] - ox) * ix, t2 = (hi[0] - ox) * ix;
         float t3 = (lo[1] - oy) * iy, t4 = (hi[1] - oy) * iy;
         float t5 = (lo[2] - oz) * iz, t6 = (hi[2] - oz) * iz;
@@ -485,7 +477,7 @@ struct Tracer {
         float tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
         float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
         tnear = tn;
-        return tf >= fmaxf(tn, 0.0f) && tn <= limf;
+        return __ballot(tf >= fmaxf(tn, 0.0f)) & __ballot(tn <= limf);
     }
 
     // Start one scene query for this lane (kind == Q_NONE: lane does not start one).  Q_CLOSEST fills
@@ -688,7 +680,12 @@ struct Tracer {
     // lanes walk independently until the last one is done.
     __device__ void traverse(bool shadow, const Ray &r, bool point_light, double light_d2, double light_dist) {
         if (EXH) return;
-        if (__ballot(armed) == 0ull) return;
+        // (lane yes/no values of the set-up are wave masks in scalar registers, as in begin(): as `bool`s they went through 0/1
+        // vector registers and back at every use)
+        typedef unsigned long long mask_t;
+        const mask_t m_armed = __ballot(armed);
+        if (m_armed == 0ull) return;
+        const mask_t m_shadow_q = __ballot(shadow);
         // reciprocal direction in fp32 (1 ulp): every use below is a conservative cull, never a result
         const float ix = __builtin_amdgcn_rcpf((float)r.d.x), iy = __builtin_amdgcn_rcpf((float)r.d.y), iz = __builtin_amdgcn_rcpf((float)r.d.z);
         TIME_DECL;
@@ -711,8 +708,9 @@ struct Tracer {
                          "s"(me.flo[1]), "s"(me.flo[2]), "s"(me.fhi[0]), "s"(me.fhi[1]), "s"(me.fhi[2]));
             if (me.froot == FNODE_NONE) continue;
             // a shadow query skips Emmit objects and stops at its first occluder
-            const bool want = armed && !(shadow && (occ || !me.occluder));
-            if (__ballot(want) == 0ull) continue;
+            unsigned long long m_occ = __ballot(occ);
+            const mask_t m_want = m_armed & ~(m_shadow_q & (me.occluder ? m_occ : ~0ull));
+            if (m_want == 0ull) continue;
             const double lim = shadow ? light_dist : bt;
             // root cull in mesh-centred fp32.  The origin may be far from the mesh, so its rounding error
             // (2^-24 of its distance) is added to the box as an explicit margin.
@@ -721,10 +719,10 @@ struct Tracer {
             float lo[3] = {me.flo[0] - mg, me.flo[1] - mg, me.flo[2] - mg};
             float hi[3] = {me.fhi[0] + mg, me.fhi[1] + mg, me.fhi[2] + mg};
             float tn_root;
-            if (COUNT && want) cnt.c[CNT_NODES]++;
-            const bool enter = fbox(lo, hi, cxo, cyo, czo, ix, iy, iz, f32_up(lim), tn_root) && want;
-            const unsigned long long em = __ballot(enter);  // lanes that enter this mesh
+            if (COUNT && __builtin_amdgcn_inverse_ballot_w64(m_want)) cnt.c[CNT_NODES]++;
+            const mask_t em = m_want & fbox_mask(lo, hi, cxo, cyo, czo, ix, iy, iz, f32_up(lim), tn_root);  // lanes that enter this mesh
             if (em == 0ull) continue;
+            const bool enter = __builtin_amdgcn_inverse_ballot_w64(em);
             // shift the origin to (just before) the entry point, so that its fp32 rounding error inside the
             // traversal (2^-24 of the mesh size) is far inside the 2^-18 inflation of the boxes
             w.t_enter = tn_root > 0 ? tn_root * 0.99999905f : 0.0f;
@@ -749,36 +747,30 @@ struct Tracer {
             // ends when its last lane is done, after about as many visits as its longest ray needed.  Boxes only cull, the
             // triangle tests and the tie rule are the per-lane path's, so the answer is the same.  Waves whose rays
             // neither share an octant nor form a narrow cone (reflections off the model) keep the per-lane walk below.
-            // The entering lanes are walked as a SEQUENCE of packets: the first lane not yet walked leads, and every remaining
-            // lane whose direction lies within a cone around the leader's joins its packet (all remaining lanes when they
-            // share an octant).  A coherent wave is one packet; a wave whose lanes hold rays of several kinds (shadow rays
-            // towards two lights, reflections beside shadow rays) falls apart into one packet per bundle.
-            unsigned long long g_rem = em, m_occ = __ballot(occ);
-            const float dx = (float)r.d.x, dy = (float)r.d.y, dz = (float)r.d.z;
-            const float dn = dx * dx + dy * dy + dz * dz;
-            int g_count = 0;
-            while (g_rem != 0ull) {
-                unsigned long long g_grp;
-                {
-                    const unsigned long long nx = g_rem & __ballot(ix < 0.0f), ny = g_rem & __ballot(iy < 0.0f), nz = g_rem & __ballot(iz < 0.0f);
-                    const bool same_octant = (nx == 0ull || nx == g_rem) && (ny == 0ull || ny == g_rem) && (nz == 0ull || nz == g_rem);
-                    const int lead_lane = __ffsll((unsigned long long)g_rem) - 1;
-                    const float lx = __shfl(dx, lead_lane), ly = __shfl(dy, lead_lane), lz = __shfl(dz, lead_lane);
-                    const float cosine = (dx * lx + dy * ly + dz * lz) * __builtin_amdgcn_rsqf(dn * (lx * lx + ly * ly + lz * lz));
-                    g_grp = (g_rem & __ballot(cosine > RAYHS_GROUP_COS)) | (1ull << lead_lane);
-                    g_count++;
-                    if (same_octant || g_count >= RAYHS_GROUP_MAX) g_grp = g_rem;
-#ifndef RAYHS_PACKET_GROUPS
-                    if (g_grp != g_rem) break;  // not one bundle: the per-lane walk below
+            // (Walking such a wave as a SEQUENCE of packets, one per bundle of directions, was measured and dropped: +10 % on
+            // the dragon frame, +47 % on dragon_low -- profiles/r04/experiments/packet_groups_kbench.log.)
+            bool as_packet;
+            {
+                // (the octant signs and the cone are only looked at by waves that enter: kept out of the code every round runs)
+                float dx = (float)r.d.x, dy = (float)r.d.y, dz = (float)r.d.z;
+                asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dz));
+                const mask_t nx = em & __ballot(dx < 0.0f), ny = em & __ballot(dy < 0.0f), nz = em & __ballot(dz < 0.0f);
+                const bool same_octant = (nx == 0ull || nx == em) && (ny == 0ull || ny == em) && (nz == 0ull || nz == em);
+                // ... or into a narrow cone (within ~25 degrees) around the first entering ray's direction: shadow rays
+                // converging on a near light straddle an axis without being any less of a bundle
+                const int lead_lane = __ffsll((unsigned long long)em) - 1;
+                const float lx = __shfl(dx, lead_lane), ly = __shfl(dy, lead_lane), lz = __shfl(dz, lead_lane);
+                const float cosine = (dx * lx + dy * ly + dz * lz) * __builtin_amdgcn_rsqf((dx * dx + dy * dy + dz * dz) * (lx * lx + ly * ly + lz * lz));
+                as_packet = same_octant || (em & ~__ballot(cosine > 0.9f)) == 0ull;
+            }
+#ifdef RAYHS_PACKET_ALWAYS
+            as_packet = true;
 #endif
-                }
-                g_rem &= ~g_grp;
-                if (COUNT && __builtin_amdgcn_inverse_ballot_w64(g_grp)) { LOOP_TICK(42); }
-                {
+            if (as_packet) {
                 const stack_ptr wstack = stack - (int)(__lane_id());  // lane 0's column serves as the wave's stack
                 // (lane yes/no values are wave masks in scalar registers, as in begin())
-                unsigned long long m_live = g_grp;
-                const unsigned long long m_shadow_lanes = __ballot(shadow), m_point_lanes = __ballot(point_light);
+                unsigned long long m_live = em;
+                const unsigned long long m_shadow_lanes = m_shadow_q, m_point_lanes = __ballot(point_light);
                 // (Requesting the next node's record before the leaves of the current visit are tested -- the scalar-cache round
                 // trip beside the triangle tests instead of after them -- was tried: the second record's 16 scalar registers on
                 // top of a triangle's 18 spilled 60 more SGPRs into vector lanes, 5.37 -> 5.90 ms.)
@@ -865,13 +857,11 @@ struct Tracer {
                     cur = next;
                     if (m_live == 0ull) break;
                 }
-                }
+                occ = __builtin_amdgcn_inverse_ballot_w64(m_occ);
+                TIME_ADD(13);
+                continue;
             }
-            occ = __builtin_amdgcn_inverse_ballot_w64(m_occ);
-            TIME_ADD(13);
-            if (g_rem == 0ull) continue;
 #endif
-#ifndef RAYHS_PACKET_GROUPS
             if (enter) w.t_cur = me.froot;
             TIME_ADD(12);
             while (true) {
@@ -936,7 +926,6 @@ struct Tracer {
                 TIME_ADD(14);
                 if (__ballot(w.traversing()) == 0ull) break;
             }
-#endif
         }
     }
 };
