@@ -159,6 +159,8 @@ static int check_desc(const rayhs_scene_desc *d, int &tree_depth) {
     // the kernels address records as base + 32-bit byte offset (largest record: 128 B per triangle, 64 B per node)
     if (d->n_tris > (1 << 25) || d->n_nodes > (1 << 25))
         return set_error(RAYHS_ERR_INVALID, "scene too large: at most 2^25 triangles and tree nodes are supported");
+    // (the shading state keeps a hit's material kind in bits 28..30 of its object index)
+    if (d->n_objects > (1 << 25)) return set_error(RAYHS_ERR_INVALID, "scene too large: at most 2^25 objects are supported");
     // an array may be NULL only when its count is zero
     struct { const void *p; int64_t n; const char *name; } arrays[] = {
         {d->obj_geom_kind, d->n_objects, "obj_geom_kind"}, {d->obj_geom_index, d->n_objects, "obj_geom_index"},

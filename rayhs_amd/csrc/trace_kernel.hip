@@ -303,6 +303,12 @@ template <typename T> DEV const T &rec(const T *base, int index) {
     return *(const T *)((const char *)base + (unsigned)index * (unsigned)sizeof(T));
 }
 
+// wave-uniform reads of a record through the scalar cache: base + UNSIGNED 32-bit byte offset, which the scalar load takes as
+// its offset register (a signed index costs a sign extension, a 64-bit shift and a 64-bit add per fetch)
+template <typename T> DEV const T __attribute__((address_space(4))) &crec(const T *base, int index) {
+    return *(cptr<T>)((unsigned long long)base + (unsigned long long)((unsigned)index * (unsigned)sizeof(T)));
+}
+
 template <bool EXH, bool COUNT, typename StackT>
 struct Tracer {
     typedef StackT __attribute__((address_space(3))) *stack_ptr;
@@ -777,7 +783,7 @@ struct Tracer {
                 int cur = me.froot, sp = 0;
                 while (true) {
                     LOOP_TICK(40);
-                    const auto &nd = as_const(fnodes)[cur];
+                    const auto &nd = crec(fnodes, cur);
                     const int c0 = nd.c0, c1 = nd.c1;
                     float tn0, tn1;
                     const unsigned long long b0 = pbox_mask(nd.b0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0);
@@ -813,7 +819,7 @@ struct Tracer {
                         unsigned long long m_leaf_occ = 0;
                         const int ref = ~c, first = ref >> 3, n = ref & 7;
                         for (int k = first; k < first + n; k++) {
-                            const auto &tr = as_const(ftris)[k];
+                            const auto &tr = crec(ftris, k);
                             if (COUNT) cnt.c[CNT_TRIS] += __builtin_amdgcn_inverse_ballot_w64(m_mine) ? 1 : 0;
                             if (__builtin_amdgcn_inverse_ballot_w64(m_mine)) { LOOP_TICK(30); }
                             double t, u, v;
@@ -983,7 +989,7 @@ static __device__ __forceinline__ void trace_body() {
     Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
     int qkind = Q_NONE;
     bool q_point = false; double q_d2 = 0, q_dist = 0;
-    int c_obj = 0, c_li = 0;
+    int c_obj = 0, c_li = 0;  // object being shaded (its material kind in bits 28..30: the light loop's end asks for it again) and light index
     bool occluded = false;
 
     // Work items are (pixel, sample) pairs: item / spp is a pixel slot in 8x8-tile order (slot >> 6 = tile,
@@ -1145,14 +1151,17 @@ static __device__ __forceinline__ void trace_body() {
                         for (int k = 0; k < 3; k++) { h_tri.p0[k] = q.p0[k]; h_tri.e1[k] = q.e1[k]; h_tri.e2[k] = q.e2[k]; }
                         const DTriAttr &at = rec(a_arr, tr.btri);
                         h_n0 = ld3(at.n0); h_n1 = ld3(at.n1); h_n2 = ld3(at.n2);
-                    }
+                    } else if (tr.bprim >= 0) h_n0 = ld3(rec(SC.planes, tr.bprim).n);   // a plane's normal,
+                    else h_n0 = ld3(rec(SC.spheres, -tr.bprim - 2).c);                  // a sphere's centre: the same round trip
                     asm volatile("" ::: "memory");
                     if (COUNT) cnt.c[CNT_SHADED]++;
-                    c_obj = tr.bobj;
+                    c_obj = tr.bobj | (ob.mat_kind << 28);  // (abi.cpp: fewer than 2^25 objects)
                     const V3 c_p = add(ray.o, scl(tr.bt, ray.d));  // rayAt (src/Geometry.hs:27-29)
                     V3 c_n;
                     double hu = 0, hv = 0;
                     const int mat_kind = ob.mat_kind;
+                    // (a flat colour goes to its context slot at once: six registers less across the triangle test below)
+                    if ((mat_kind == 1 || mat_kind == 2) && ob.cmap_kind == 0) cx_store3(cx, CX_CD, ld3(ob.c1));
                     if (mat_kind == 0 || mat_kind == 2 || mat_kind == 4) PARK_V(ray.d);  // Mirror, Plastic, Transparent: the view direction is read again after the light loop
                     const bool need_uv = ((mat_kind == 1 || mat_kind == 2) && ob.cmap_kind != 0) || mat_kind == 6;
                     if (is_tri) {
@@ -1167,19 +1176,17 @@ static __device__ __forceinline__ void trace_body() {
                             hv = u * at.uv1[1] + v * at.uv2[1] + w * at.uv0[1];
                         }
                     } else if (tr.bprim >= 0) {  // re-derive the analytic hit from t
-                        const auto &pl = rec(SC.planes, tr.bprim);
-                        c_n = ld3(pl.n);
-                        if (need_uv) { V3 rel = sub(c_p, ld3(pl.p)); hu = dot(ld3(pl.t), rel); hv = dot(ld3(pl.b), rel); }
+                        c_n = h_n0;
+                        if (need_uv) { const auto &pl = rec(SC.planes, tr.bprim); V3 rel = sub(c_p, ld3(pl.p)); hu = dot(ld3(pl.t), rel); hv = dot(ld3(pl.b), rel); }
                     } else {
-                        const auto &s = rec(SC.spheres, -tr.bprim - 2);
-                        c_n = unit(sub(c_p, ld3(s.c)));
+                        c_n = unit(sub(c_p, h_n0));
                         if (need_uv) { const UV2 uv = polar_uv(c_n); hu = uv.u; hv = uv.v; }  // src/Geometry.hs:96
                     }
                     // the context of the hit being shaded waits in LDS while its rays are traced
                     cx_store3(cx, CX_P, c_p); cx_store3(cx, CX_N, c_n);
                     // irradiance (src/RayHs.hs:107-147)
                     if (mat_kind == 1 || mat_kind == 2) {  // Diffuse, Plastic
-                        cx_store3(cx, CX_CD, ob.cmap_kind == 0 ? ld3(ob.c1) : color_at_slow(as_const(SC.objects), tr.bobj, SC.texels, hu, hv));
+                        if (ob.cmap_kind != 0) cx_store3(cx, CX_CD, color_at_slow(as_const(SC.objects), tr.bobj, SC.texels, hu, hv));
                         cx_store3(cx, CX_A, mk(0, 0, 0));  // accumDiffuse folds from black
                         c_li = 0;
                         step = A_LIGHT_NEXT;
@@ -1205,7 +1212,7 @@ static __device__ __forceinline__ void trace_body() {
                 step = A_LIGHT_NEXT;
             } else if (state == ST_EXIT) {
                 // the transmitted ray's exit point (src/RayHs.hs:140-143)
-                const auto &ob = rec(SC.objects, c_obj);
+                const auto &ob = rec(SC.objects, c_obj & 0x0fffffff);
                 bool have = false;
                 if (tr.bobj >= 0) {
                     V3 outp = add(ray.o, scl(tr.bt, ray.d));
@@ -1282,7 +1289,7 @@ static __device__ __forceinline__ void trace_body() {
                         if (q_point) { V3 dd = sub(ray.o, ld3(L.v)); q_d2 = dot(dd, dd); }  // sqrDist origin p (src/RayHs.hs:87)
                         if (COUNT) cnt.c[CNT_SHADOW]++;
                         qkind = Q_SHADOW; state = ST_SHADOW; step = A_QUERY_READY;  // p, n, cd and the running sum A stay parked in LDS
-                    } else if (rec(SC.objects, c_obj).mat_kind == 1) {
+                    } else if ((c_obj >> 28) == 1) {
                         cx_store3(cx, CX_A, add(scl(0.2, c_cd), cx_load3(cx, CX_A)));  // Diffuse (src/RayHs.hs:111-114)
                         step = A_RETURN;
                     } else { spec_with_A = true; step = A_SPEC; }  // Plastic (src/RayHs.hs:117-120)
@@ -1293,7 +1300,7 @@ static __device__ __forceinline__ void trace_body() {
             TIME_ADD(2);  // light section
             if (step == A_SPEC) {
                 // fresnel * specular (src/RayHs.hs:99-104,119,124,132)
-                const auto &ob = rec(SC.objects, c_obj);
+                const auto &ob = rec(SC.objects, c_obj & 0x0fffffff);
                 const V3 c_n = cx_load3(cx, CX_N);
                 V3 c_v = LOAD_V();
                 double F = fresnel(ob.fr, dot(c_n, neg(c_v)), (PRM.flags_dev & 2) != 0);
