@@ -48,8 +48,12 @@ WORKLOADS = {
 }
 STRIPE_ROWS = 8
 # frames enqueued at a time, each on its own scene handle and stream (see main): two when there is a gather to hide
-# behind the next frame's trace (N > 1), one on a single GPU (two buy nothing there and blur a profiler's per-kernel rows)
-IN_FLIGHT = int(os.environ.get("RAYHS_BENCH_IN_FLIGHT", "0")) or (2 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 1)
+# behind the next frame's trace (N > 1), three when a rank's share is an eighth of the frame or less (a share that small ends
+# with most of the chip idle behind its slowest chunks; measured on one GPU, tools/overlap_frames.py, 1/8 share of the
+# 1080p / 16 spp frame: 1.05 ms per frame with one in flight, 0.73 with two, 0.69 with three; 1/4 share: 1.34 / 1.29 / 1.29),
+# one on a single GPU (two buy nothing there and blur a profiler's per-kernel rows)
+_WORLD = int(os.environ.get("WORLD_SIZE", "1"))
+IN_FLIGHT = int(os.environ.get("RAYHS_BENCH_IN_FLIGHT", "0")) or (3 if _WORLD >= 8 else 2 if _WORLD > 1 else 1)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 # issue roof (same guide: 256 CUs x 4 SIMDs, 2400 MHz max clock; one instruction per SIMD-cycle with all wave slots occupied,
 # profiles/r04/micro/issue_rates.txt)

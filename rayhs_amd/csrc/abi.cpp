@@ -603,6 +603,7 @@ static void make_camera(const rayhs_camera &c, int width, int height, DCamera &o
 // id: tells one list from another in the tile-order cache.
 struct StripeList { const int32_t *d_map = nullptr; int n_stripes = 0, rows = 0, id = 0; };
 
+static uint64_t mix64(uint64_t x);
 static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_render_params *p, const StripeList *sl, DCamera &dc, DParams &dp,
                           int &variant, bool &exact, int &grid, size_t &lds) {
     if (!s || !cam || !p) return set_error(RAYHS_ERR_INVALID, "NULL argument");
@@ -616,7 +617,8 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     if ((p->flags & RAYHS_FLAG_EXHAUSTIVE) && !(p->flags & RAYHS_FLAG_COUNT)) return set_error(RAYHS_ERR_INVALID, "RAYHS_FLAG_EXHAUSTIVE needs RAYHS_FLAG_COUNT");
     make_camera(*cam, p->width, p->height, dc);
     std::memset(&dp, 0, sizeof dp);
-    dp.width = p->width; dp.height = p->height; dp.max_depth = p->max_depth; dp.spp = p->spp; dp.seed = p->seed;
+    dp.width = p->width; dp.height = p->height; dp.max_depth = p->max_depth; dp.spp = p->spp;
+    dp.seed = mix64(p->seed + 0x9e3779b97f4a7c15ULL);  // the sampler's seed term (include/rayhs.h, rayhs_sample01), mixed once here instead of per sample
     dp.row0 = p->row0; dp.n_rows = rows;
     dp.stripe_rows = p->stripe_rows; dp.stripe_rank = p->stripe_rank; dp.stripe_count = p->stripe_count;
     if (sl) { dp.stripe_map = sl->d_map; dp.stripe_rank = sl->id; dp.stripe_count = 0; }  // rank / count are unused with a list (the rank slot keys the tile-order cache)

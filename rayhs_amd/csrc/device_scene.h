@@ -123,7 +123,7 @@ struct DCamera {
 
 struct DParams {
     int32_t width, height, max_depth, spp;
-    uint64_t seed;
+    uint64_t seed;                    // mix64(seed + 0x9e3779b97f4a7c15): the seed term of rayhs_sample01, mixed on the host
     int32_t row0, n_rows;             // first candidate row, rows rendered by this call
     int32_t stripe_rows, stripe_rank, stripe_count;
     int32_t out_format;

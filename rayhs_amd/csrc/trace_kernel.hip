@@ -508,9 +508,13 @@ struct Tracer {
         const mask_t m_point = __ballot(active && shadow && point_light);  // shadow queries towards a point light
         mask_t m_occ = 0;  // lanes whose shadow query has found an occluder
         const double a = dot(r.d, r.d);
-        const double a_margin = a * (1.0 - 1e-4);  // (the margin of the "beyond the light" shortcut below, folded in once per query)
-        const double o_max = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z));
-        const double o_guard = (o_max * o_max) * 1e-18;
+        // (what only the "beyond the light" shortcut of point-light shadow queries reads; rounds without such a query skip it)
+        double a_margin = 0, o_guard = 0;
+        if (m_point != 0ull) {
+            a_margin = a * (1.0 - 1e-4);
+            const double o_max = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z));
+            o_guard = (o_max * o_max) * 1e-18;
+        }
         const int n_planes = SC.n_planes, n_spheres = SC.n_spheres, n_meshes = SC.n_meshes;
         const auto planes = as_const(SC.planes);
         auto plane_range = [&](auto axis_tag, int i, const int end) {
@@ -1396,7 +1400,7 @@ static __device__ __forceinline__ void trace_body() {
                 }
                 double fx = (double)px, fy = (double)yrow;
                 if (prm.spp > 1) {
-                    const uint64_t seed_mixed = mix64(prm.seed + 0x9e3779b97f4a7c15ULL);
+                    const uint64_t seed_mixed = prm.seed;  // (mix64(seed + golden ratio), done by the launcher)
                     uint64_t pixel = (uint64_t)px + (uint64_t)prm.width * (uint64_t)yrow;
                     fx = fx + (sample01(seed_mixed, pixel, (uint32_t)sample, 0, (uint32_t)prm.spp) - 0.5);
                     fy = fy + (sample01(seed_mixed, pixel, (uint32_t)sample, 1, (uint32_t)prm.spp) - 0.5);
