@@ -3,7 +3,7 @@
 # first-frame vs steady state, stripe balance, static estimate vs measured tile costs, phase times and section
 # utilisation of the development builds, end-to-end CLI timings.  Outputs under gpurun_out/<tag>_*; copy to profiles/<tag>/.
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out
 export TMPDIR=/tmp
 mkdir -p $out

@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/pmc_extra.sh r02 dragon'   ->  gpurun_out/<tag>_<wl>_pmcx_*/ ; python tools/pmc_extra_summary.py <tag> <wl>
 set -o pipefail
 export TMPDIR=/tmp
-tag=${1:-r03}; wl=${2:-dragon}
+tag=${1:-r04}; wl=${2:-dragon}
 pre=gpurun_out/${tag}_${wl}_pmcx
 rm -rf ${pre}_*
 pmc() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d ${pre}_$name -- python3 tools/kbench.py $wl 4 > /dev/null 2>&1 || exit 3; }
