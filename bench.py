@@ -87,7 +87,8 @@ def profile_counters(workload, kernel_ms):
     d = json.load(open(files[-1]))
     src = {"profile": os.path.relpath(files[-1], ROOT), "kernel_source_sha256": d.get("kernel_source_sha256"),
            "profile_kernel_ms": (d.get("timed_launches") or {}).get("avg_ms")}
-    src["matches_this_kernel"] = bool(src["kernel_source_sha256"]) and src["kernel_source_sha256"] == kernel_source_sha256()
+    src["matches_this_kernel"] = (bool(src["kernel_source_sha256"]) and src["kernel_source_sha256"] == kernel_source_sha256()
+                                  and not os.environ.get("RAYHS_BENCH_IGNORE_PROFILE"))  # (test hook: rehearse the live-counter fallback)
     c = next((v for k, v in d.get("pmc_mean_per_launch", {}).items() if "count" not in k), None)
     if not src["matches_this_kernel"] or not c or "hbm_bytes_per_launch_read_doubled" not in c:
         return src, None
@@ -119,6 +120,46 @@ def profile_counters(workload, kernel_ms):
         "scalar_dcache_hit_rate": c.get("scalar_dcache_hit_rate"),
         "scalar_icache_hit_rate": c.get("scalar_icache_hit_rate"),
     }
+
+
+def live_instruction_counts(workload, fma):
+    """Fallback when no committed profile matches this kernel source: count the trace kernel's instructions NOW, with two
+    short rocprofv3 --pmc passes of this very script as child processes (counters in their own runs, nothing else traced;
+    `--pmc-child` keeps the children from doing the same).  Returns the fields the issue roof needs, or None."""
+    import csv, glob, shutil, subprocess, tempfile
+    if os.environ.get("RAYHS_BENCH_NO_LIVE_PMC") or not shutil.which("rocprofv3"):
+        return None
+    passes = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"],
+              ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"]]
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="rayhs_pmc_", dir="/tmp")
+    try:
+        for i, counters in enumerate(passes):
+            out = os.path.join(tmp, f"p{i}")
+            cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--workload", workload,
+                   "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-4k", "--pmc-child"] + (["--fma"] if fma else [])
+            r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            if r.returncode != 0:
+                return None
+            acc = {}
+            for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Kernel_Name"].startswith("rayhs_trace") and "count" not in row["Kernel_Name"]:
+                        acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for c in counters:
+                if c not in acc:
+                    return None
+                vals[c] = sum(acc[c]) / len(acc[c])
+        insts = sum(vals[c] for c in passes[0])
+        arith = vals["SQ_INSTS_VALU_ADD_F64"] + vals["SQ_INSTS_VALU_MUL_F64"] + vals["SQ_INSTS_VALU_FMA_F64"]
+        trans = vals["SQ_INSTS_VALU_TRANS_F64"]
+        return {"insts_per_launch": insts, "issue_slots_per_launch": (insts - arith - trans) + 1.93 * arith + 6.0 * trans,
+                "valu_f64_share_of_insts": (arith + trans) / vals["SQ_INSTS_VALU"], "salu_per_valu": vals["SQ_INSTS_SALU"] / vals["SQ_INSTS_VALU"],
+                "branches_per_valu": vals["SQ_INSTS_BRANCH"] / vals["SQ_INSTS_VALU"], "valu_insts_per_launch": vals["SQ_INSTS_VALU"]}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def golden_digest(workload):
@@ -173,6 +214,7 @@ def main():
     ap.add_argument("--fma", action="store_true", help="use the fused-multiply-add kernels (not bit-exact with the reference)")
     ap.add_argument("--no-4k", dest="also_4k", action="store_false",
                     help="skip the extra (untimed for `value`) leg on BASELINE configs[4], the 4K / 64 spp frame")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # a counter pass of live_instruction_counts(): no nested passes
     ap.add_argument("--verify", action="store_true",
                     help="rank 0 also renders the whole frame by itself and checks that the gathered frame is identical")
     args = ap.parse_args()
@@ -362,6 +404,15 @@ def main():
         # algorithmic bytes per launch / kernel time against the HBM peak.  The scene is cache-resident, so that figure is
         # served by L1 / scalar cache / L2 and exceeds the HBM peak: a work rate, not a bandwidth.
         src, ctr = profile_counters(args.workload, kernel_ms) if world == 1 else ({"profile": None, "matches_this_kernel": False}, None)
+        if ctr is None and world == 1 and not args.pmc_child:
+            # no committed profile of THIS kernel source: count its instructions now (two short rocprofv3 --pmc child runs);
+            # the HBM / cache / wave-life figures, which need five more passes, stay null
+            live = live_instruction_counts(args.workload, args.fma)
+            if live:
+                names = ("traffic", "hbm_traffic_frac", "hbm_read_frac", "hbm_write_bytes", "l2_hit_rate", "valu_busy", "valu_lane_util", "wave_wait_frac",
+                         "valu_pipe_frac", "fp64_tflops_issued", "wave_issuing_frac", "wave_waitcnt_frac", "scalar_dcache_hit_rate", "scalar_icache_hit_rate")
+                ctr = {**{k: None for k in names}, "fp64_peak_tflops": 78.6, "waves_per_simd": 4, **live}
+                src = {**src, "live_pmc_passes_in_this_run": True}
         sec = kernel_ms * 1e-3
         slots = ctr and ctr.get("issue_slots_per_launch")
         issue_achieved = slots / sec / 1e9 if slots else None
