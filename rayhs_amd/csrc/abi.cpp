@@ -628,6 +628,7 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     dp.wave_resolve = (p->spp > 1 && 64 % p->spp == 0 && !std::getenv("RAYHS_NO_WAVE_RESOLVE")) ? 1 : 0;
     auto log2_exact = [](int v) { int s = 0; while ((1 << s) < v) s++; return (1 << s) == v ? s : -1; };
     dp.spp_shift = log2_exact(p->spp);
+    dp.inv_spp = 1.0 / (double)p->spp;
     dp.stripe_shift = log2_exact(p->stripe_rows);
     dp.tiles_x = (p->width + 7) / 8;
     dp.inv_tiles_x = 1.0f / (float)dp.tiles_x;

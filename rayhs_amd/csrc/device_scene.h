@@ -140,6 +140,7 @@ struct DParams {
     const int32_t *stripe_map;        // NULL: round-robin stripes (stripe_rank / stripe_count); else the global stripe index of every
                                       // local stripe of this launch, ascending (rayhs_multi: cost-balanced ownership)
     int32_t flags_dev, pad_dev;       // development switches of the helper kernels (bit 0: rayhs_static_costs emits its raw feature); bit 1: RAYHS_FLAG_POW5_SQMUL
+    double inv_spp;                   // 1.0 / spp (the same IEEE division the reference's average performs, done once on the host)
     float *tile_cost;                 // per tile: longest time (100 MHz ticks) one of its chunks took in THIS frame (NULL: not recorded)
 };
 

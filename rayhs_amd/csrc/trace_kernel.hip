@@ -261,7 +261,7 @@ template <class CAM> DEV Ray ray_from_pixel(const CAM &c, double px, double py) 
 }
 
 // lane states between scene queries
-enum : int { ST_NEW_SAMPLE = 0, ST_HIT, ST_SHADOW, ST_EXIT, ST_DONE };
+enum : int { ST_HIT = 1, ST_SHADOW, ST_EXIT, ST_DONE };
 // frame kinds
 enum : int { FR_PLASTIC = 0, FR_MIRROR, FR_TRANS_WAIT_RADIANCE, FR_TRANS_WAIT_SPEC };
 // query kinds
@@ -1042,6 +1042,8 @@ static __device__ __forceinline__ void trace_body() {
     const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime(), mt0_ = __builtin_amdgcn_s_memtime();
 #endif
     while (true) {
+        bool refilled = false;  // (wave-uniform) this round's rays are the primary rays of a chunk just drawn
+        qkind = Q_NONE;
         if (__ballot(state != ST_DONE) == 0ull) {  // every lane is done: finish the chunk the wave held, draw the next one
             const auto &prm = kargs()->prm;
             if (chunk_pending) {
@@ -1057,7 +1059,7 @@ static __device__ __forceinline__ void trace_body() {
                             sum = add(add(add(add(sum, a), b), c), d);
                         }
                         for (; k < prm.spp; k++) sum = add(sum, at(k));
-                        store_pixel(kargs()->out, prm.out_format, (size_t)lrow * (size_t)prm.width + (size_t)px, scl(1.0 / (double)prm.spp, sum));
+                        store_pixel(kargs()->out, prm.out_format, (size_t)lrow * (size_t)prm.width + (size_t)px, scl(prm.inv_spp, sum));
                     }
                 }
                 // how long the chunk took, for the next frame's work order (costs are >= 0: their bit patterns order like the values)
@@ -1110,21 +1112,46 @@ static __device__ __forceinline__ void trace_body() {
                 int px, lrow, sample;
                 locate(px, lrow, sample);
                 item_valid = px < prm.width && lrow < prm.n_rows;
-                if (item_valid) state = ST_NEW_SAMPLE;
                 chunk_pending = true;
+                // Every lane of a fresh chunk starts its sample here and now (a lane only ever starts one right after a refill):
+                // the item was located a moment ago, and the rounds in between never ask "is this lane starting a sample?"
+                if (item_valid) {
+                    // pixelCoord (src/Image.hs:31-32) + optional sample offset (src/RayHs.hs:178-188)
+                    int yrow;
+                    // local row -> image row (stripe interleave, include/rayhs.h)
+                    if (prm.stripe_count == 1 && prm.stripe_map == nullptr) yrow = prm.row0 + lrow;
+                    else {
+                        const int s_local = prm.stripe_shift >= 0 ? lrow >> prm.stripe_shift : lrow / prm.stripe_rows;
+                        const int in_stripe = lrow - s_local * prm.stripe_rows;
+                        // round-robin ownership, or an explicit list of this device's stripes (rayhs_multi: cost-balanced)
+                        const int s_global = prm.stripe_map ? prm.stripe_map[s_local] : s_local * prm.stripe_count + prm.stripe_rank;
+                        yrow = prm.row0 + s_global * prm.stripe_rows + in_stripe;
+                    }
+                    double fx = (double)px, fy = (double)yrow;
+                    if (prm.spp > 1) {
+                        const uint64_t seed_mixed = prm.seed;  // (mix64(seed + golden ratio), done by the launcher)
+                        uint64_t pixel = (uint64_t)px + (uint64_t)prm.width * (uint64_t)yrow;
+                        fx = fx + (sample01(seed_mixed, pixel, (uint32_t)sample, 0, (uint32_t)prm.spp) - 0.5);
+                        fy = fy + (sample01(seed_mixed, pixel, (uint32_t)sample, 1, (uint32_t)prm.spp) - 0.5);
+                    }
+                    ray = ray_from_pixel(kargs()->cam, fx, fy);
+                    fsp = 0;
+                    if (COUNT) cnt.c[CNT_PRIMARY]++;
+                    qkind = Q_CLOSEST; state = ST_HIT;
+                }
+                refilled = true;
             }
         }
 
         // ---- advance: consume the last query's answer, run shading up to the next query.
-        // Straight-line sections (hit / shadow / exit -> lights -> specular -> return -> next sample).  The sections talk to
+        // Straight-line sections (hit / shadow / exit -> lights -> specular -> return).  The sections talk to
         // each other through the lane's LDS context slots (P, N, CD, A -- A doubles as the radiance being returned), not
         // through registers: every V3 that crossed a section boundary in registers had to be copied into place on each
         // path that reaches the join, and those copies were a quarter of the vector instructions of a round.  The
         // compiler barriers between the sections keep it from turning the LDS hand-over back into register copies.
         TIME_ADD(0);  // refill
-        qkind = Q_NONE;
         occluded = tr.occ;
-        if (state != ST_DONE) {
+        if (!refilled && state != ST_DONE) {
             LOOP_TICK(16);
             enum : int { A_NONE, A_LIGHT_NEXT, A_SPEC, A_RETURN, A_QUERY_READY };
             int step = A_NONE;
@@ -1383,33 +1410,6 @@ static __device__ __forceinline__ void trace_body() {
                 } while (step == A_RETURN);
             }
 
-            asm volatile("" ::: "memory");
-            if (state == ST_NEW_SAMPLE) {
-                // pixelCoord (src/Image.hs:31-32) + optional sample offset (src/RayHs.hs:178-188)
-                const auto &prm = kargs()->prm;
-                int px, lrow, sample, yrow;
-                locate(px, lrow, sample);
-                // local row -> image row (stripe interleave, include/rayhs.h)
-                if (prm.stripe_count == 1 && prm.stripe_map == nullptr) yrow = prm.row0 + lrow;
-                else {
-                    const int s_local = prm.stripe_shift >= 0 ? lrow >> prm.stripe_shift : lrow / prm.stripe_rows;
-                    const int in_stripe = lrow - s_local * prm.stripe_rows;
-                    // round-robin ownership, or an explicit list of this device's stripes (rayhs_multi: cost-balanced)
-                    const int s_global = prm.stripe_map ? prm.stripe_map[s_local] : s_local * prm.stripe_count + prm.stripe_rank;
-                    yrow = prm.row0 + s_global * prm.stripe_rows + in_stripe;
-                }
-                double fx = (double)px, fy = (double)yrow;
-                if (prm.spp > 1) {
-                    const uint64_t seed_mixed = prm.seed;  // (mix64(seed + golden ratio), done by the launcher)
-                    uint64_t pixel = (uint64_t)px + (uint64_t)prm.width * (uint64_t)yrow;
-                    fx = fx + (sample01(seed_mixed, pixel, (uint32_t)sample, 0, (uint32_t)prm.spp) - 0.5);
-                    fy = fy + (sample01(seed_mixed, pixel, (uint32_t)sample, 1, (uint32_t)prm.spp) - 0.5);
-                }
-                ray = ray_from_pixel(kargs()->cam, fx, fy);
-                fsp = 0;
-                if (COUNT) cnt.c[CNT_PRIMARY]++;
-                qkind = Q_CLOSEST; state = ST_HIT;
-            }
         }
 
         // ---- the single scene-query site shared by every lane of the wave.  The compiler barriers keep

@@ -64,14 +64,13 @@ marks = [("(unattributed)", 1),
          ("traverse(): per-lane walk", find("if (enter) w.t_cur = me.froot;")),
          ("workspace / context helpers", find("// ---- global per-lane workspace")),
          ("trace_body(): set-up", find("static __device__ __forceinline__ void trace_body()")),
-         ("main loop: refill", find("if (__ballot(state != ST_DONE) == 0ull)")),
+         ("main loop: refill + new sample", find("if (__ballot(state != ST_DONE) == 0ull)")),
          ("hit section", find("if (state == ST_HIT) {")),
          ("shadow-return section", find("} else if (state == ST_SHADOW) {")),
          ("exit section", find("} else if (state == ST_EXIT) {")),
          ("light section", find("if (step == A_LIGHT_NEXT) {")),
          ("specular section", find("if (step == A_SPEC) {")),
          ("return section", find("if (step == A_RETURN) {")),
-         ("new sample", find("if (state == ST_NEW_SAMPLE) {")),
          ("query site + epilogue", find("// ---- the single scene-query site")),
          ("end", len(src) + 1)]
 print(f"{'section':52s} {'VALU':>6s} {'SALU':>6s} {'mem':>5s}")
