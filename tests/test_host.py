@@ -395,3 +395,29 @@ def test_cli_argument_errors_mirror_the_reference():
     assert "Failed to read scene" in r.stderr                                       # RayHs.hs:226
     r = rayhs_amd.run_cli(["-o", "data/nope.json"], cwd=ROOT)                       # bare -o keeps out.ppm, arg is the scene
     assert r.returncode == 1 and r.stdout.startswith("Loading scene from data/nope.json...")
+
+
+def test_committed_profiles_carry_the_issue_roofline_bench_py_prices_with():
+    # bench.py's `roofline` (the binding roof: instruction issue) takes the trace kernel's instruction counts from
+    # profiles/rNN/<workload>/summary.json when that profile was taken on this very kernel source.  The derived fields must
+    # be there and consistent with the raw counters (tools/summarize_profiles.py), and the fraction must be a fraction.
+    import glob
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "dragon", "summary.json")))
+    assert files, "no committed profile of the default workload"
+    d = json.load(open(files[-1]))
+    c = next(v for k, v in d["pmc_mean_per_launch"].items() if "count" not in k)
+    classes = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")
+    insts = sum(c[k] for k in classes)
+    arith = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"]
+    trans = c["SQ_INSTS_VALU_TRANS_F64"]
+    cost = d["issue_cost_simd_cycles"]
+    assert c["insts_per_launch"] == pytest.approx(insts)
+    assert c["issue_slots_per_launch"] == pytest.approx((insts - arith - trans) * cost["any"] + arith * cost["fp64"] + trans * cost["fp64_trans"])
+    assert 0 < c["issue_frac"] <= 1 and 0 < c["scalar_dcache_hit_rate"] <= 1
+    # priced at bench.py's peak (1024 SIMDs x 2.4 GHz) with the profile's own kernel time the fraction stays a fraction
+    frac = c["issue_slots_per_launch"] / (d["timed_launches"]["avg_ms"] * 1e-3) / 1e9 / bench.ISSUE_PEAK_GSLOTS
+    assert 0 < frac <= 1
+    if d.get("kernel_source_sha256") != bench.kernel_source_sha256():
+        pytest.skip("the committed profile was taken on another kernel source: bench.py will count instructions live (rocprofv3 --pmc child runs); "
+                    "re-run tools/profile_round.sh + tools/summarize_profiles.py before the round ends")
