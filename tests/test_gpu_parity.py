@@ -354,11 +354,15 @@ def test_multi_device_frame_equals_the_single_device_frame_one_gpu_rehearsal(pol
 
 
 @pytest.mark.skipif(L.load().rayhs_device_count() < 2, reason="needs two physical GPUs (peer access, cross-device events)")
-def test_multi_device_on_two_physical_gpus_equals_the_single_device_frame():
+@pytest.mark.parametrize("create", ["serial", "one thread per device"])
+def test_multi_device_on_two_physical_gpus_equals_the_single_device_frame(create, monkeypatch):
     # what the one-GPU rehearsals above cannot execute: hipDeviceEnablePeerAccess, the peer writes of rayhs_scatter_stripes
     # into a frame that lives on devices[0] (the library's own, and a caller-owned d_out), and the cross-device
-    # hipStreamWaitEvent on every device's `done` event.  Runs wherever the box shows >= 2 GPUs.
+    # hipStreamWaitEvent on every device's `done` event.  Runs wherever the box shows >= 2 GPUs -- with the devices brought
+    # up one after the other (the default) and on one thread each (RAYHS_MULTI_PARALLEL_CREATE, opt-in until this has passed).
     import torch
+    if create != "serial":
+        monkeypatch.setenv("RAYHS_MULTI_PARALLEL_CREATE", "1")
     n = min(L.load().rayhs_device_count(), 8)
     rd = RenderDesc("scenes/dragon_low_1080p.json")
     single = Rendering(rd)
