@@ -30,7 +30,7 @@
 //     batch of loads and one wave-level branch per primitive; planes are grouped by the axis of their
 //     normal so that an axis-aligned wall costs one product per dot product.
 //   * Mesh traversal uses the BVH of bvh_build.cpp: 64-byte nodes holding both children's boxes as
-//     mesh-centred fp32 planes (one packed fused multiply-add per axis, culling only).  A wave whose
+//     mesh-centred fp32 planes (one fused multiply-add per plane, culling only).  A wave whose
 //     entering rays share an octant or form a narrow cone walks it as ONE packet (one node, one stack,
 //     scalar fetches for the whole wave); otherwise every lane walks on its own with a stack of
 //     inner-node indices in LDS (level-major: bank-conflict free), nearest child first, leaves
@@ -449,13 +449,17 @@ struct Tracer {
         return take;
     }
 
-    // slab test of one child box: t = plane * A + B (A = 1/d, B = -o/d), one packed fused multiply-add per axis.
+    // slab test of one child box: t = plane * A + B (A = 1/d, B = -o/d), one fused multiply-add per plane.  (Two v_fma_f32, not
+    // one v_pk_fma_f32: the packed form wants every coefficient twice -- 12 registers instead of 6 across the walks -- and at 4
+    // waves per SIMD it issues at the fp64 rate, three times slower than two plain ones: profiles/r04/micro/issue_rates.txt.
+    // 62 -> 42 spilled registers, dragon frame -1.6 %, dragon_low -2.3 %: profiles/r04/experiments/scalar_fma_boxes.log.)
     // Culling only: the stored boxes are inflated far beyond the fp32 rounding of these operations (abi.cpp).
     typedef float f2 __attribute__((ext_vector_type(2)));
     template <class BP> __device__ __forceinline__ bool pbox(BP b, float ax, float ay, float az, float bx, float by, float bz, float limf, float &tnear) {
-        const f2 x = __builtin_elementwise_fma((f2){b[0], b[1]}, (f2){ax, ax}, (f2){bx, bx});
-        const f2 y = __builtin_elementwise_fma((f2){b[2], b[3]}, (f2){ay, ay}, (f2){by, by});
-        const f2 z = __builtin_elementwise_fma((f2){b[4], b[5]}, (f2){az, az}, (f2){bz, bz});
+        f2 x, y, z;
+        x.x = __builtin_fmaf(b[0], ax, bx); x.y = __builtin_fmaf(b[1], ax, bx);
+        y.x = __builtin_fmaf(b[2], ay, by); y.y = __builtin_fmaf(b[3], ay, by);
+        z.x = __builtin_fmaf(b[4], az, bz); z.y = __builtin_fmaf(b[5], az, bz);
         float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fminf(z.x, z.y));
         float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fmaxf(z.x, z.y));
         tnear = tn;
@@ -464,9 +468,10 @@ struct Tracer {
 
     // the same test as a wave mask (each ballot is of one comparison, which then writes the mask itself)
     template <class BP> __device__ __forceinline__ unsigned long long pbox_mask(BP b, float ax, float ay, float az, float bx, float by, float bz, float limf, float &tnear) {
-        const f2 x = __builtin_elementwise_fma((f2){b[0], b[1]}, (f2){ax, ax}, (f2){bx, bx});
-        const f2 y = __builtin_elementwise_fma((f2){b[2], b[3]}, (f2){ay, ay}, (f2){by, by});
-        const f2 z = __builtin_elementwise_fma((f2){b[4], b[5]}, (f2){az, az}, (f2){bz, bz});
+        f2 x, y, z;
+        x.x = __builtin_fmaf(b[0], ax, bx); x.y = __builtin_fmaf(b[1], ax, bx);
+        y.x = __builtin_fmaf(b[2], ay, by); y.y = __builtin_fmaf(b[3], ay, by);
+        z.x = __builtin_fmaf(b[4], az, bz); z.y = __builtin_fmaf(b[5], az, bz);
         float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fminf(z.x, z.y));
         float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fmaxf(z.x, z.y));
         tnear = tn;
