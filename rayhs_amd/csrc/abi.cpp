@@ -351,13 +351,16 @@ static int pack_scene(const rayhs_scene_desc *desc, PackedScene &pk) {
         // fp32 rounding of the kernel's slab test (origin, reciprocal direction, one fused multiply-add per plane)
         auto fbox32 = [&](const double *lo, const double *hi, float *b) {
             for (int c = 0; c < 3; c++) {
-                if (lo[c] <= hi[c]) { b[2 * c] = round_down_f32((lo[c] - ctr[c]) - infl); b[2 * c + 1] = round_up_f32((hi[c] - ctr[c]) + infl); }
-                else { b[2 * c] = b[2 * c + 1] = std::numeric_limits<float>::quiet_NaN(); }  // absent child (reference FNODE_NONE): a NaN box fails every slab test, so the walks need no test of their own
+                // (every child has a box: bvh_build.cpp gives the missing sibling of a one-leaf mesh that leaf's box and no
+                // triangles; the kernel's box test relies on finite planes, so anything else is clamped to a point)
+                const bool ok = lo[c] <= hi[c] && std::isfinite(lo[c]) && std::isfinite(hi[c]);
+                b[2 * c] = ok ? round_down_f32((lo[c] - ctr[c]) - infl) : 0.0f;
+                b[2 * c + 1] = ok ? round_up_f32((hi[c] - ctr[c]) + infl) : 0.0f;
             }
         };
         // inner references index the global node array; leaf references ~((first << 3) | count) index the
         // global BVH-ordered triangle array
-        auto child = [&](int c) { return c == FNODE_NONE ? FNODE_NONE : c >= 0 ? c + node_base : ~((((~c) >> 3) + tri_base) << 3 | ((~c) & 7)); };
+        auto child = [&](int c) { return c == FNODE_NONE || c == FNODE_EMPTY ? FNODE_EMPTY : c >= 0 ? c + node_base : ~((((~c) >> 3) + tri_base) << 3 | ((~c) & 7)); };
         for (const FNodeBuild &nb : bvh.nodes) {
             FNode fn;
             std::memset(&fn, 0, sizeof fn);

@@ -181,8 +181,9 @@ void build_fast_bvh(const double *tri_pos, const std::vector<int> &tri_ids, Fast
         bl.nodes.emplace_back();
         FNodeBuild &nd = bl.nodes[0];
         std::memcpy(nd.lo0, all.lo, sizeof nd.lo0); std::memcpy(nd.hi0, all.hi, sizeof nd.hi0);
-        for (int k = 0; k < 3; k++) { nd.lo1[k] = std::numeric_limits<double>::infinity(); nd.hi1[k] = -nd.lo1[k]; }
-        nd.c0 = ~((0 << 3) | count); nd.c1 = INT32_MIN;
+        // ... and the second slot is an EMPTY leaf (no triangles) with the same box: every stored box stays finite
+        std::memcpy(nd.lo1, all.lo, sizeof nd.lo1); std::memcpy(nd.hi1, all.hi, sizeof nd.hi1);
+        nd.c0 = ~((0 << 3) | count); nd.c1 = ~0;
         root = 0;
     } else root = bl.build(0, count, 0);
     out.root = root;

@@ -28,13 +28,15 @@ static constexpr int32_t DNODE_LEAF = (int32_t)0x80000000;
 // multiply-add per axis,  t = plane * (1/d) + (-o/d),  with no decode step.  (32-byte nodes with 16-bit grid
 // coordinates were 2 % slower once the waves were coherent: 12 conversions per visit cost more than the bytes.)
 // Child reference: >= 0 inner node, < 0 leaf ~((first << 3) | count) into the BVH-ordered triangle
-// array, INT32_MIN = no child (its box is NaN: it fails every slab test, so the walks never look at the reference).
+// array.  A node always has two children: the missing sibling of a mesh that is one leaf is the EMPTY LEAF -1
+// (~0: no triangles) with that leaf's box, so that every stored box is finite and the walks test no reference.
 struct alignas(16) FNode {
     float b0[6], b1[6];
     int32_t c0, c1;
     int32_t pad_[2];
 };
-static constexpr int32_t FNODE_NONE = (int32_t)0x80000000;
+static constexpr int32_t FNODE_NONE = (int32_t)0x80000000;  // "no node": an empty mesh's root, the walks' idle marker
+static constexpr int32_t FNODE_EMPTY = -1;                  // the empty leaf
 
 // 80 B: what triangleIntersection reads (src/Mesh.hs:59-72): p0, e1 = p1-p0, e2 = p2-p0,
 // plus the triangle's place in the reference's order for exact-t ties.

@@ -449,6 +449,12 @@ struct Tracer {
         return take;
     }
 
+    // Does the ray's stretch [0, limit] meet the box it enters at tn and leaves at tf?  ONE comparison: max(tn, 0) <= min(tf, limit)
+    // (a limit below zero means that nothing in the box can beat the hit already found).  The operands are never NaN: every
+    // stored box is finite (an absent child is an EMPTY LEAF with its sibling's box, bvh_build.cpp), and a ray with a zero, huge
+    // or non-finite component never gets here (begin() sends it through the reference tree).
+    static __device__ __forceinline__ bool met(float tn, float tf, float limf) { return fmaxf(tn, 0.0f) <= fminf(tf, limf); }
+
     // slab test of one child box: t = plane * A + B (A = 1/d, B = -o/d), one fused multiply-add per plane.  (Two v_fma_f32, not
     // one v_pk_fma_f32: the packed form wants every coefficient twice -- 12 registers instead of 6 across the walks -- and at 4
     // waves per SIMD it issues at the fp64 rate, three times slower than two plain ones: profiles/r04/micro/issue_rates.txt.
@@ -463,7 +469,7 @@ struct Tracer {
         float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fminf(z.x, z.y));
         float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fmaxf(z.x, z.y));
         tnear = tn;
-        return tf >= fmaxf(tn, 0.0f) && tn <= limf;
+        return met(tn, tf, limf);
     }
 
     // the same test as a wave mask (each ballot is of one comparison, which then writes the mask itself)
@@ -475,7 +481,7 @@ struct Tracer {
         float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fminf(z.x, z.y));
         float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fmaxf(z.x, z.y));
         tnear = tn;
-        return __ballot(tf >= fmaxf(tn, 0.0f)) & __ballot(tn <= limf);
+        return __ballot(met(tn, tf, limf));
     }
 
     // conservative fp32 slab test of the mesh bounds (root cull) as a wave mask; t is relative to the given origin
@@ -484,11 +490,11 @@ struct Tracer {
         float t1 = (lo[0] - ox) * ix, t2 = (hi[0] - ox) * ix;
         float t3 = (lo[1] - oy) * iy, t4 = (hi[1] - oy) * iy;
         float t5 = (lo[2] - oz) * iz, t6 = (hi[2] - oz) * iz;
-        // fminf/fmaxf drop a NaN operand (0 * inf when the origin lies on a slab plane of a zero direction axis)
+        // (no NaN among these for the lanes that matter: begin() arms only finite rays with every |d| component above 1e-25)
         float tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
         float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
         tnear = tn;
-        return __ballot(tf >= fmaxf(tn, 0.0f)) & __ballot(tn <= limf);
+        return __ballot(met(tn, tf, limf));
     }
 
     // Start one scene query for this lane (kind == Q_NONE: lane does not start one).  Q_CLOSEST fills
@@ -513,12 +519,19 @@ struct Tracer {
         const mask_t m_point = __ballot(active && shadow && point_light);  // shadow queries towards a point light
         mask_t m_occ = 0;  // lanes whose shadow query has found an occluder
         const double a = dot(r.d, r.d);
-        // (what only the "beyond the light" shortcut of point-light shadow queries reads; rounds without such a query skip it)
-        double a_margin = 0, o_guard = 0;
+        // The "beyond the light" shortcut of point-light shadow queries (rounds without such a query skip it).  A plane met at
+        // |t| > K cannot occlude when K^2 a exceeds the light's squared distance by a margin: inFrontOfLight compares that
+        // distance with |o - (o + t d)|^2 = t^2 a (1 +- 1e-15) +- |t| |o| 2^-50.  K = sqrt(light_d2) * 1.006 covers the
+        // approximate root (v_sqrt_f64, ~1e-8) and any a >= 0.99 (directions towards point lights are unit vectors; the
+        // shortcut is off otherwise); K >= 2e-9 |o| keeps the cancellation term below 1e-6 t^2 a.  Then |num| > |den| K
+        // implies |num / den| > K (1 - 2^-52): one product and one comparison per plane, no reciprocal.  A NaN or infinite
+        // K never passes (the exact test decides).
+        double beyond_k = __builtin_inf();
         if (m_point != 0ull) {
-            a_margin = a * (1.0 - 1e-4);
-            const double o_max = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z));
-            o_guard = (o_max * o_max) * 1e-18;
+            const double o_floor = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z)) * 2e-9;
+            double k = __builtin_amdgcn_sqrt(light_d2) * 1.006;
+            k = o_floor > k ? o_floor : k;  // (a NaN k stays NaN)
+            beyond_k = a >= 0.99 ? k : __builtin_inf();
         }
         const int n_planes = SC.n_planes, n_spheres = SC.n_spheres, n_meshes = SC.n_meshes;
         const auto planes = as_const(SC.planes);
@@ -540,16 +553,10 @@ struct Tracer {
             if (__builtin_amdgcn_inverse_ballot_w64(m_consider)) { LOOP_TICK(18); }
             double num, den;
             plane_terms<AXIS>(nk, pk, pn, pp, r, num, den);
-            // a shadow query only asks whether the hit lies in front of the light: with an approximate quotient
-            // (v_rcp_f64, ~1e-8) a plane whose squared hit distance exceeds the light's by more than 1e-4 of it is
-            // settled without the division.  (in_front forms |o - (o + t d)|^2; its cancellation error stays
-            // below that margin unless the origin is 1e9 hit distances away from zero -- then we divide.)
+            // a shadow query only asks whether the hit lies in front of the light: a plane met beyond K (above) is settled
+            // without the division
             mask_t m_beyond = 0;
-            if (m_point != 0ull) {
-                const double q = num * __builtin_amdgcn_rcp(den);
-                const double q2 = q * q, s_far = q2 * a;
-                m_beyond = m_point & __ballot(q2 * a_margin > light_d2) & __ballot(s_far > o_guard);
-            }
+            if (m_point != 0ull) m_beyond = m_point & __ballot(fabs(num) > fabs(den) * beyond_k);
             // (every ballot is of ONE comparison: the compare then writes the mask itself; a ballot of `a && b` goes through
             // a 0/1 vector register)
             const mask_t m_wanted = m_consider & ~m_beyond & quotient_may_be_positive(num, den);
@@ -604,7 +611,11 @@ struct Tracer {
             // through the origin it computes 0 * inf = NaN and may reject a box the ray does touch
             // (src/KDTree.hs:39-56).  Its boxes are therefore NOT a conservative cull for such rays, and only
             // its own tree reproduces its answer: those (rare) lanes walk the reference tree, here and now.
-            const bool by_reference = EXH || !(fabs(r.d.x) > 1e-25) || !(fabs(r.d.y) > 1e-25) || !(fabs(r.d.z) > 1e-25);  // also keeps 1/d finite in fp32
+            // A ray with a huge or non-finite component goes the same way: the fp32 coordinates of the fast structure could
+            // overflow or turn into NaN for it, and its box tests rely on having neither (met()); the reference's answer for a
+            // NaN ray -- every comparison false: every box passed, every triangle "hit" -- is its own tree's anyway.
+            const double magnitude = ((((fabs(r.o.x) + fabs(r.o.y)) + fabs(r.o.z)) + fabs(r.d.x)) + fabs(r.d.y)) + fabs(r.d.z);
+            const bool by_reference = EXH || !(fabs(r.d.x) > 1e-25) || !(fabs(r.d.y) > 1e-25) || !(fabs(r.d.z) > 1e-25) || !(magnitude < 1e30);  // also keeps 1/d finite in fp32
             if (EXH || __ballot(active && by_reference) != 0ull)
                 occluded = meshes_reference(active && by_reference, shadow, r, point_light, light_d2, occluded);
             // leave the meshes to the fast traversal
@@ -665,9 +676,9 @@ struct Tracer {
     // (wave-uniform visit: the fields are scalar loads and the child references stay in SGPRs).
     template <class ND> __device__ __forceinline__ void visit(Walk &w, const ND &nd, float limf) {
         float tn0, tn1;
-        const bool h0 = pbox(nd.b0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0);  // (an absent child's box is NaN: never met)
+        const bool h0 = pbox(nd.b0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0);  // (an absent child is an empty leaf)
         const bool h1 = pbox(nd.b1, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn1);
-        if (COUNT) cnt.c[CNT_NODES] += (nd.c0 != FNODE_NONE) + (nd.c1 != FNODE_NONE);
+        if (COUNT) cnt.c[CNT_NODES] += (nd.c0 != FNODE_EMPTY) + (nd.c1 != FNODE_EMPTY);
         const bool near0 = tn0 <= tn1;
         const bool l0 = h0 && nd.c0 < 0, l1 = h1 && nd.c1 < 0;    // hit leaves
         const bool i0 = h0 && nd.c0 >= 0, i1 = h1 && nd.c1 >= 0;  // hit inner children
@@ -797,8 +808,8 @@ struct Tracer {
                     float tn0, tn1;
                     const unsigned long long b0 = pbox_mask(nd.b0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0);
                     const unsigned long long b1 = pbox_mask(nd.b1, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn1);
-                    const unsigned long long m0 = b0 & m_live, m1 = b1 & m_live;  // (an absent child's box is NaN: no lane meets it)
-                    if (COUNT) cnt.c[CNT_NODES] += __builtin_amdgcn_inverse_ballot_w64(m_live) ? (c0 != FNODE_NONE) + (c1 != FNODE_NONE) : 0;
+                    const unsigned long long m0 = b0 & m_live, m1 = b1 & m_live;  // (an absent child is an empty leaf: no triangles to test)
+                    if (COUNT) cnt.c[CNT_NODES] += __builtin_amdgcn_inverse_ballot_w64(m_live) ? (c0 != FNODE_EMPTY) + (c1 != FNODE_EMPTY) : 0;
                     // the child that more of the lanes that hit something would take first: (ca, ma) before (cb, mb).  The choice is
                     // made by the scalar unit (left to the compiler the comparison of the two population counts went through a
                     // vector compare and back)
@@ -1589,7 +1600,7 @@ DEV int upper_boxes_met(const DScene &sc, const DMesh &me, V3 o, V3 d) {
         for (int ch = 0; ch < 2; ch++) {
             const float *b = ch ? nd.b1 : nd.b0;
             const int c = ch ? nd.c1 : nd.c0;
-            if (c == FNODE_NONE) continue;
+            if (c == FNODE_EMPTY) continue;
             const float t1 = (b[0] - ox) * ix, t2 = (b[1] - ox) * ix, t3 = (b[2] - oy) * iy, t4 = (b[3] - oy) * iy, t5 = (b[4] - oz) * iz, t6 = (b[5] - oz) * iz;
             const float tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6)), tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
             if (!(tf >= fmaxf(tn, 0.0f))) continue;
