@@ -404,7 +404,7 @@ static int pack_scene(const rayhs_scene_desc *desc, PackedScene &pk) {
             p.b[0] = p.t[1] * p.n[2] - p.t[2] * p.n[1];
             p.b[1] = p.t[2] * p.n[0] - p.t[0] * p.n[2];
             p.b[2] = p.t[0] * p.n[1] - p.t[1] * p.n[0];
-            p.obj = i; p.occluder = occl;
+            p.obj = i; p.occluder = occl; p.shadow_skip = occl ? 0ull : ~0ull;
         } else if (d.obj_geom_kind[i] == RAYHS_GEOM_SPHERE) {
             if (sphere_used[(size_t)g]++) return set_error(RAYHS_ERR_INVALID, "sphere %d referenced by two objects", g);
             DSphere &s = spheres[(size_t)g];

@@ -53,13 +53,16 @@ struct alignas(16) DTriAttr {
     int32_t pad;
 };
 
-struct DPlane {   // src/Geometry.hs:62, 70-79
-    double p[3], n[3];
-    int32_t obj, occluder;          // scene object index; 0 for Emmit (never an occluder, src/RayHs.hs:81).  Next to p and n:
-                                    // the query loop then gets everything it needs from one scalar-load round trip
+struct alignas(32) DPlane {   // src/Geometry.hs:62, 70-79
+    // the first 32 bytes are what the query loop reads of an axis-aligned plane: ONE scalar load
+    int32_t obj, occluder;          // scene object index; 0 for Emmit (never an occluder, src/RayHs.hs:81)
+    uint64_t shadow_skip;           // occluder ? 0 : ~0 -- the lanes' "shadow query" mask is OR-ed with it (an Emmit plane is
+                                    // skipped by every shadow query, an occluder only by those already occluded)
     double nk, pk;                  // planes whose normal has ONE non-zero component k (DScene.plane_axis_end): n[k], p[k]
+    double p[3], n[3];
     double t[3], b[3];              // b = cross t n (only the UV of a shaded hit reads these)
 };
+static_assert(sizeof(DPlane) == 128, "plane record: 32-byte head + four vectors");
 struct DSphere {  // src/Geometry.hs:63, 81-96
     double c[3], r2;                // r2 = r ^ 2
     int32_t obj, occluder;

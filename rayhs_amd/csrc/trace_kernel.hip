@@ -363,7 +363,9 @@ struct Tracer {
     // and one compare, instead of four fp64 compares and three mask operations; zeros and NaNs of equal sign bit pass and
     // are rejected by the exact test.
     static __device__ __forceinline__ unsigned long long quotient_may_be_positive(double num, double den) {  // wave mask
-        return __ballot((__double2hiint(num) ^ __double2hiint(den)) >= 0);
+        int x;
+        asm("v_xor_b32 %0, %1, %2" : "=v"(x) : "v"(__double2hiint(num)), "v"(__double2hiint(den)));  // (left to the compiler this became a 64-bit exclusive-or and a 64-bit compare)
+        return __ballot(x >= 0);
     }
     // Sphere (src/Geometry.hs:78-85): the discriminant first; the roots (a square root and two divisions) only when
     // some lane of the wave has delta >= 0.
@@ -542,21 +544,26 @@ struct Tracer {
             // compiler re-loaded `occluder` and `obj` inside each branch that mentions them: four dependent scalar-cache
             // round trips per plane)
             const auto &rec_ = planes[i];
-            const int pl_obj = rec_.obj, pl_occluder = rec_.occluder;
+            // (the 32-byte head as ONE eight-dword scalar load: field by field the compiler asks for 2 + 4 + 2 dwords)
+            typedef int i8v __attribute__((ext_vector_type(8)));
+            const i8v head = *(cptr<i8v>)&rec_;
+            const int pl_obj = head[0], pl_occluder = head[1];
+            const mask_t pl_shadow_skip = ((mask_t)(unsigned)head[3] << 32) | (mask_t)(unsigned)head[2];
             double nk = 0, pk = 0;
             V3 pn = mk(0, 0, 0), pp = mk(0, 0, 0);
-            if (AXIS < 3) { nk = rec_.nk; pk = rec_.pk; asm volatile("" :: "s"(pl_obj), "s"(pl_occluder), "s"(nk), "s"(pk)); }
-            else { pn = ld3(rec_.n); pp = ld3(rec_.p); asm volatile("" :: "s"(pl_obj), "s"(pl_occluder), "s"(pn.x), "s"(pn.y), "s"(pn.z), "s"(pp.x), "s"(pp.y), "s"(pp.z)); }
-            // outside the exhaustive kernels a shadow query skips Emmit objects and stops at its first occluder
-            const mask_t m_consider = EXH ? m_active : (m_active & ~(m_shadow & (pl_occluder ? m_occ : ~0ull)));
+            if (AXIS < 3) { nk = __hiloint2double(head[5], head[4]); pk = __hiloint2double(head[7], head[6]); asm volatile("" :: "s"(pl_obj), "s"(pl_occluder), "s"(nk), "s"(pk), "s"(pl_shadow_skip)); }
+            else { pn = ld3(rec_.n); pp = ld3(rec_.p); asm volatile("" :: "s"(pl_obj), "s"(pl_occluder), "s"(pl_shadow_skip), "s"(pn.x), "s"(pn.y), "s"(pn.z), "s"(pp.x), "s"(pp.y), "s"(pp.z)); }
+            // outside the exhaustive kernels a shadow query skips Emmit objects and stops at its first occluder (the record
+            // carries "not an occluder" as a ready-made mask: one OR instead of a compare and three selects)
+            const mask_t m_consider = EXH ? m_active : (m_active & ~(m_shadow & (m_occ | pl_shadow_skip)));
             if (COUNT) cnt.c[CNT_PRIMS] += __builtin_amdgcn_inverse_ballot_w64(m_consider) ? 1 : 0;
             if (__builtin_amdgcn_inverse_ballot_w64(m_consider)) { LOOP_TICK(18); }
             double num, den;
             plane_terms<AXIS>(nk, pk, pn, pp, r, num, den);
             // a shadow query only asks whether the hit lies in front of the light: a plane met beyond K (above) is settled
             // without the division
-            mask_t m_beyond = 0;
-            if (m_point != 0ull) m_beyond = m_point & __ballot(fabs(num) > fabs(den) * beyond_k);
+            // (unconditional: K is infinite in rounds without such a query, and two instructions cost less than the branches)
+            const mask_t m_beyond = m_point & __ballot(fabs(num) > fabs(den) * beyond_k);
             // (every ballot is of ONE comparison: the compare then writes the mask itself; a ballot of `a && b` goes through
             // a 0/1 vector register)
             const mask_t m_wanted = m_consider & ~m_beyond & quotient_may_be_positive(num, den);
