@@ -533,17 +533,23 @@ struct Tracer {
             const double o_floor = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z)) * 2e-9;
             double k = __builtin_amdgcn_sqrt(light_d2) * 1.006;
             k = o_floor > k ? o_floor : k;  // (a NaN k stays NaN)
-            beyond_k = a >= 0.99 ? k : __builtin_inf();
+            beyond_k = (active && shadow && point_light && a >= 0.99) ? k : __builtin_inf();  // (per lane: other lanes never pass)
         }
         const int n_planes = SC.n_planes, n_spheres = SC.n_spheres, n_meshes = SC.n_meshes;
         const auto planes = as_const(SC.planes);
-        auto plane_range = [&](auto axis_tag, int i, const int end) {
+        // lanes that consider a plane: the closest-hit queries, and the shadow queries still open unless the plane is Emmit
+        const mask_t m_closest = EXH ? m_active : (m_active & ~m_shadow);
+        mask_t m_shadow_open = EXH ? 0ull : (m_active & m_shadow);  // (shrinks as occluders are found)
+        auto plane_range = [&](auto axis_tag, const int begin_, const int end) {
             constexpr int AXIS = decltype(axis_tag)::value;
-            for (; i < end; i++) {
+            // (the loop runs on the record's byte offset: one scalar add, one compare and the load's own offset operand)
+            for (unsigned off_ = (unsigned)begin_ * (unsigned)sizeof(DPlane); off_ < (unsigned)end * (unsigned)sizeof(DPlane); off_ += (unsigned)sizeof(DPlane)) {
+            unsigned off = off_;
+            asm volatile("" : "+s"(off));  // (keeps the offset 32 bits wide: widened, it costs a 64-bit add per plane and a second counter)
             // everything the test reads of the plane, fetched as ONE batch of scalar loads at the top (left to itself the
             // compiler re-loaded `occluder` and `obj` inside each branch that mentions them: four dependent scalar-cache
             // round trips per plane)
-            const auto &rec_ = planes[i];
+            const auto &rec_ = *(cptr<DPlane>)((unsigned long long)planes + (unsigned long long)off);
             // (the 32-byte head as ONE eight-dword scalar load: field by field the compiler asks for 2 + 4 + 2 dwords)
             typedef int i8v __attribute__((ext_vector_type(8)));
             const i8v head = *(cptr<i8v>)&rec_;
@@ -555,7 +561,7 @@ struct Tracer {
             else { pn = ld3(rec_.n); pp = ld3(rec_.p); asm volatile("" :: "s"(pl_obj), "s"(pl_occluder), "s"(pl_shadow_skip), "s"(pn.x), "s"(pn.y), "s"(pn.z), "s"(pp.x), "s"(pp.y), "s"(pp.z)); }
             // outside the exhaustive kernels a shadow query skips Emmit objects and stops at its first occluder (the record
             // carries "not an occluder" as a ready-made mask: one OR instead of a compare and three selects)
-            const mask_t m_consider = EXH ? m_active : (m_active & ~(m_shadow & (m_occ | pl_shadow_skip)));
+            const mask_t m_consider = m_closest | (m_shadow_open & ~pl_shadow_skip);
             if (COUNT) cnt.c[CNT_PRIMS] += __builtin_amdgcn_inverse_ballot_w64(m_consider) ? 1 : 0;
             if (__builtin_amdgcn_inverse_ballot_w64(m_consider)) { LOOP_TICK(18); }
             double num, den;
@@ -563,7 +569,7 @@ struct Tracer {
             // a shadow query only asks whether the hit lies in front of the light: a plane met beyond K (above) is settled
             // without the division
             // (unconditional: K is infinite in rounds without such a query, and two instructions cost less than the branches)
-            const mask_t m_beyond = m_point & __ballot(fabs(num) > fabs(den) * beyond_k);
+            const mask_t m_beyond = __ballot(fabs(num) > fabs(den) * beyond_k);
             // (every ballot is of ONE comparison: the compare then writes the mask itself; a ballot of `a && b` goes through
             // a 0/1 vector register)
             const mask_t m_wanted = m_consider & ~m_beyond & quotient_may_be_positive(num, den);
@@ -576,10 +582,11 @@ struct Tracer {
                 if (pl_occluder != 0 && (m_hit & m_shadow) != 0ull) {
                     // (in_front is true for every directional light)
                     m_occ |= m_hit & m_shadow & (~m_point | __ballot(in_front(r, t, true, light_d2)));
+                    if (!EXH) m_shadow_open &= ~m_occ;
                 }
                 const mask_t m_better = m_hit & ~m_shadow & (__ballot(t < bt) | (__ballot(t == bt) & __ballot(pl_obj < bobj)));
                 const bool better = __builtin_amdgcn_inverse_ballot_w64(m_better);
-                bt = better ? t : bt; bobj = better ? pl_obj : bobj; bprim = better ? i : bprim;
+                bt = better ? t : bt; bobj = better ? pl_obj : bobj; bprim = better ? (int)(off / (unsigned)sizeof(DPlane)) : bprim;
             }
             }
         };
