@@ -509,6 +509,8 @@ static int upload_scene(const PackedScene &pk, int device, rayhs_scene **out) {
     s->d.n_planes = (int)pk.planes.size();
     for (int a = 0; a < 3; a++) s->d.plane_axis_end[a] = pk.plane_axis_end[a];
     s->d.n_spheres = (int)pk.spheres.size();
+    s->d.sphere_occluders = 0;
+    for (const DSphere &sp : pk.spheres) s->d.sphere_occluders += sp.occluder ? 1 : 0;
     s->d.n_meshes = (int)pk.meshes.size();
     s->d.n_objects = pk.n_objects;
     s->d.n_lights = pk.n_lights;

@@ -110,7 +110,8 @@ struct DScene {
     int32_t n_planes, n_spheres, n_meshes, n_objects, n_lights, n_nodes, n_tris, n_fnodes;
     // planes are stored grouped: [0, plane_axis_end[0]) have a normal along x, [.., [1]) along y, [.., [2]) along z, the
     // rest are in general position (the query loop runs a body specialised per group; ties go by object index)
-    int32_t plane_axis_end[3], pad_axis;
+    int32_t plane_axis_end[3];
+    int32_t sphere_occluders;  // spheres that can occlude (not Emmit): with none, a round of shadow queries skips the sphere loop
 };
 
 // Camera constants of rayFromPixel / unproject / lookAt (src/Projection.hs:22-46,

@@ -536,6 +536,8 @@ struct Tracer {
             beyond_k = (active && shadow && point_light && a >= 0.99) ? k : __builtin_inf();  // (per lane: other lanes never pass)
         }
         const int n_planes = SC.n_planes, n_spheres = SC.n_spheres, n_meshes = SC.n_meshes;
+        // |o| + |d| component by component: below 1e30 every component is finite and small enough for the fp32 boxes
+        const double magnitude = ((((fabs(r.o.x) + fabs(r.o.y)) + fabs(r.o.z)) + fabs(r.d.x)) + fabs(r.d.y)) + fabs(r.d.z);
         const auto planes = as_const(SC.planes);
         // lanes that consider a plane: the closest-hit queries, and the shadow queries still open unless the plane is Emmit
         const mask_t m_closest = EXH ? m_active : (m_active & ~m_shadow);
@@ -592,7 +594,7 @@ struct Tracer {
         };
         if (m_active != 0ull) {
             // a ray with a non-finite component (0 * inf = NaN in the reference's sums) forces the general form on everyone
-            const bool all_finite = __ballot(active && !isfinite(((r.d.x + r.d.y) + r.d.z) + ((r.o.x + r.o.y) + r.o.z))) == 0ull;
+            const bool all_finite = __ballot(active && !(magnitude < 1e30)) == 0ull;
             const int ex = all_finite ? SC.plane_axis_end[0] : 0, ey = all_finite ? SC.plane_axis_end[1] : 0, ez = all_finite ? SC.plane_axis_end[2] : 0;
             plane_range(std::integral_constant<int, 0>(), 0, ex);
             plane_range(std::integral_constant<int, 1>(), ex, ey);
@@ -600,12 +602,14 @@ struct Tracer {
             plane_range(std::integral_constant<int, 3>(), ez, n_planes);
         }
         const auto spheres = as_const(SC.spheres);
-        for (int i = 0; i < n_spheres && m_active != 0ull; i++) {
+        // (a round of shadow queries skips the loop when no sphere can occlude: light bulbs are Emmit)
+        const mask_t m_sphere_lanes = (EXH || SC.sphere_occluders != 0) ? m_active : m_closest;
+        for (int i = 0; i < n_spheres && m_sphere_lanes != 0ull; i++) {
             // (one batch of scalar loads per sphere, as for the planes)
             struct { double c[3], r2; int obj, occluder; } s;
             { const auto &q = spheres[i]; s.c[0] = q.c[0]; s.c[1] = q.c[1]; s.c[2] = q.c[2]; s.r2 = q.r2; s.obj = q.obj; s.occluder = q.occluder; }
             asm volatile("" :: "s"(s.c[0]), "s"(s.c[1]), "s"(s.c[2]), "s"(s.r2), "s"(s.obj), "s"(s.occluder));
-            const mask_t m_consider = EXH ? m_active : (m_active & ~(m_shadow & (s.occluder ? m_occ : ~0ull)));
+            const mask_t m_consider = m_closest | (s.occluder ? m_shadow_open : 0ull);
             if (m_consider == 0ull) continue;
             if (COUNT) cnt.c[CNT_PRIMS] += __builtin_amdgcn_inverse_ballot_w64(m_consider) ? 1 : 0;
             if (__builtin_amdgcn_inverse_ballot_w64(m_consider)) { LOOP_TICK(22); }
@@ -613,8 +617,10 @@ struct Tracer {
             sphere_terms(s, r, a, b, delta);
             if ((m_consider & ~__ballot(delta < 0.0)) == 0ull) continue;
             const mask_t m_hit = m_consider & sphere_roots(a, b, delta, t);
-            if (s.occluder != 0 && (m_hit & m_shadow) != 0ull)
+            if (s.occluder != 0 && (m_hit & m_shadow) != 0ull) {
                 m_occ |= m_hit & m_shadow & (~m_point | __ballot(in_front(r, t, true, light_d2)));
+                if (!EXH) m_shadow_open &= ~m_occ;
+            }
             const mask_t m_better = m_hit & ~m_shadow & (__ballot(t < bt) | (__ballot(t == bt) & __ballot(s.obj < bobj)));
             const bool better = __builtin_amdgcn_inverse_ballot_w64(m_better);
             bt = better ? t : bt; bobj = better ? s.obj : bobj; bprim = better ? -(i + 2) : bprim;
@@ -628,7 +634,6 @@ struct Tracer {
             // A ray with a huge or non-finite component goes the same way: the fp32 coordinates of the fast structure could
             // overflow or turn into NaN for it, and its box tests rely on having neither (met()); the reference's answer for a
             // NaN ray -- every comparison false: every box passed, every triangle "hit" -- is its own tree's anyway.
-            const double magnitude = ((((fabs(r.o.x) + fabs(r.o.y)) + fabs(r.o.z)) + fabs(r.d.x)) + fabs(r.d.y)) + fabs(r.d.z);
             const bool by_reference = EXH || !(fabs(r.d.x) > 1e-25) || !(fabs(r.d.y) > 1e-25) || !(fabs(r.d.z) > 1e-25) || !(magnitude < 1e30);  // also keeps 1/d finite in fp32
             if (EXH || __ballot(active && by_reference) != 0ull)
                 occluded = meshes_reference(active && by_reference, shadow, r, point_light, light_d2, occluded);
