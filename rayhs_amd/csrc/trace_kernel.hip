@@ -411,6 +411,19 @@ struct Tracer {
         return !(fabs(det) < kEps || u < 0 || u > 1 || v < 0 || (u + v) > 1 || t < kEps);
     }
 
+    // the same test on a triangle held as three vectors (registers): what the hit and exit sections re-run on the winning triangle
+    static __device__ __forceinline__ bool tri_test_v(V3 p0, V3 e1, V3 e2, const Ray &r, double &t, double &u, double &v) {
+        V3 p = cross(r.d, e2);
+        double det = dot(e1, p);
+        double idet = 1 / det;
+        V3 t0 = sub(r.o, p0);
+        u = idet * dot(t0, p);
+        V3 q = cross(t0, e1);
+        v = idet * dot(r.d, q);
+        t = idet * dot(e2, q);
+        return !(fabs(det) < kEps || u < 0 || u > 1 || v < 0 || (u + v) > 1 || t < kEps);
+    }
+
     // the same test as a wave mask, straight-line (no early exit on a small determinant: its quotients are then inf or NaN,
     // and the determinant's own bit rejects the lane).  NaN operands make every comparison false, i.e. a hit, as in the
     // reference and in tri_test.
@@ -1210,11 +1223,13 @@ static __device__ __forceinline__ void trace_body() {
                     const bool some_ref = EXH || __ballot(is_tri && tr.bref) != 0ull;
                     const DTri *const t_arr = !some_ref ? SC.ftris : (tr.bref ? SC.tris : SC.ftris);
                     const DTriAttr *const a_arr = !some_ref ? SC.fattrs : (tr.bref ? SC.attrs : SC.fattrs);
-                    struct { double p0[3], e1[3], e2[3]; } h_tri;
+                    // (three vectors, not a struct of arrays: that one lived in scratch, every 16-byte piece of the triangle stored
+                    // there behind its own wait, the loads one after the other)
+                    V3 h_p0 = mk(0, 0, 0), h_e1 = h_p0, h_e2 = h_p0;
                     V3 h_n0 = mk(0, 0, 0), h_n1 = h_n0, h_n2 = h_n0;
                     if (is_tri) {
                         const DTri &q = rec(t_arr, tr.btri);
-                        for (int k = 0; k < 3; k++) { h_tri.p0[k] = q.p0[k]; h_tri.e1[k] = q.e1[k]; h_tri.e2[k] = q.e2[k]; }
+                        h_p0 = ld3(q.p0); h_e1 = ld3(q.e1); h_e2 = ld3(q.e2);
                         const DTriAttr &at = rec(a_arr, tr.btri);
                         h_n0 = ld3(at.n0); h_n1 = ld3(at.n1); h_n2 = ld3(at.n2);
                     } else if (tr.bprim >= 0) h_n0 = ld3(rec(SC.planes, tr.bprim).n);   // a plane's normal,
@@ -1232,7 +1247,7 @@ static __device__ __forceinline__ void trace_body() {
                     const bool need_uv = ((mat_kind == 1 || mat_kind == 2) && ob.cmap_kind != 0) || mat_kind == 6;
                     if (is_tri) {
                         double u, v, t_again;  // the same test on the same ray and triangle: the same doubles as during the walk
-                        tr.tri_test(h_tri, ray, t_again, u, v);
+                        tr.tri_test_v(h_p0, h_e1, h_e2, ray, t_again, u, v);
                         const double w = 1 - u - v;
                         // barycentricInterp u n1 v n2 (1-u-v) n0 (src/Mesh.hs:53-57,73-74)
                         c_n = add(add(scl(u, h_n1), scl(v, h_n2)), scl(w, h_n0));
@@ -1286,12 +1301,13 @@ static __device__ __forceinline__ void trace_body() {
                     if (tr.btri >= 0) {
                         // (one batch of loads, as in the hit section)
                         const bool some_ref = EXH || __ballot(tr.bref) != 0ull;
-                        const DTri h_tri = rec(!some_ref ? SC.ftris : (tr.bref ? SC.tris : SC.ftris), tr.btri);
+                        const DTri &h_q = rec(!some_ref ? SC.ftris : (tr.bref ? SC.tris : SC.ftris), tr.btri);
+                        const V3 h_p0 = ld3(h_q.p0), h_e1 = ld3(h_q.e1), h_e2 = ld3(h_q.e2);
                         const DTriAttr &at = rec(!some_ref ? SC.fattrs : (tr.bref ? SC.attrs : SC.fattrs), tr.btri);
                         const V3 h_n0 = ld3(at.n0), h_n1 = ld3(at.n1), h_n2 = ld3(at.n2);
                         asm volatile("" ::: "memory");
                         double u, v, t_again;
-                        tr.tri_test(h_tri, ray, t_again, u, v);
+                        tr.tri_test_v(h_p0, h_e1, h_e2, ray, t_again, u, v);
                         const double w = 1 - u - v;
                         outn = add(add(scl(u, h_n1), scl(v, h_n2)), scl(w, h_n0));
                     } else if (tr.bprim >= 0) outn = ld3(rec(SC.planes, tr.bprim).n);
