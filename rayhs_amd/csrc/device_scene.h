@@ -128,25 +128,33 @@ struct DCamera {
 };
 
 struct DParams {
-    int32_t width, height, max_depth, spp;
-    uint64_t seed;                    // mix64(seed + 0x9e3779b97f4a7c15): the seed term of rayhs_sample01, mixed on the host
-    int32_t row0, n_rows;             // first candidate row, rows rendered by this call
-    int32_t stripe_rows, stripe_rank, stripe_count;
+    // ---- the first 64 bytes are what a wave reads when it draws a chunk of work: the trace kernel fetches them with ONE scalar
+    // load (ParamsHot in trace_kernel.hip mirrors this block field by field)
+    int32_t spp;
+    int32_t spp_shift;                // log2(spp) when spp is a power of two, else -1 (the refill then divides)
+    int32_t width;
+    int32_t n_rows;                   // rows rendered by this call
+    int32_t tiles_x;                  // 8x8-pixel tiles per row of tiles
+    float inv_tiles_x;                // 1 / tiles_x: tile -> (row, column) of the tile grid without an integer division
+    int32_t n_tiles;                  // tiles over (width x n_rows)
+    int32_t wave_resolve;             // 1: spp divides 64, samples are folded inside the wave (no sample buffer)
     int32_t out_format;
-    int32_t tiles_x, n_tiles;         // 8x8-pixel tiles over (width x n_rows)
+    int32_t stripe_count;
+    int32_t row0;                     // first candidate row
+    int32_t stripe_shift;             // log2(stripe_rows) when that is a power of two, else -1
+    uint64_t seed;                    // mix64(seed + 0x9e3779b97f4a7c15): the seed term of rayhs_sample01, mixed on the host
+    double inv_spp;                   // 1.0 / spp (the same IEEE division the reference's average performs, done once on the host)
+    // ---- the rest
+    int32_t height, max_depth;
+    int32_t stripe_rows, stripe_rank;
     int32_t stack_cap;                // per-lane LDS stack entries
     int32_t ctx_slots;                // per-lane LDS context doubles: CTX_SLOTS, or CTX_SLOTS + 3 (light term too) when it fits
     int32_t frame_stride;             // threads in the grid (workspace stride)
+    int32_t flags_dev;                // development switches of the helper kernels (bit 0: rayhs_static_costs emits its raw feature); bit 1: RAYHS_FLAG_POW5_SQMUL
     double *sbuf;                     // spp > 1: per-sample radiance, 3 doubles per (pixel, sample)
-    int32_t wave_resolve;             // 1: spp divides 64, samples are folded inside the wave (no sample buffer)
-    int32_t spp_shift;                // log2(spp) when spp is a power of two, else -1 (the refill then divides)
-    int32_t stripe_shift;             // log2(stripe_rows) when that is a power of two, else -1
-    float inv_tiles_x;                // 1 / tiles_x: tile -> (row, column) of the tile grid without an integer division
     const int32_t *tile_order;        // work order of the 8x8 tiles, slowest first (NULL: scan order); from the previous frame's tile_cost
     const int32_t *stripe_map;        // NULL: round-robin stripes (stripe_rank / stripe_count); else the global stripe index of every
                                       // local stripe of this launch, ascending (rayhs_multi: cost-balanced ownership)
-    int32_t flags_dev, pad_dev;       // development switches of the helper kernels (bit 0: rayhs_static_costs emits its raw feature); bit 1: RAYHS_FLAG_POW5_SQMUL
-    double inv_spp;                   // 1.0 / spp (the same IEEE division the reference's average performs, done once on the host)
     float *tile_cost;                 // per tile: longest time (100 MHz ticks) one of its chunks took in THIS frame (NULL: not recorded)
 };
 

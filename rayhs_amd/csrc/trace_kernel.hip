@@ -100,6 +100,25 @@ static __device__ __forceinline__ cptr<KArgs> kargs() {
 }
 #define SC (kargs()->sc)
 #define PRM (kargs()->prm)
+// What a wave reads of the launch parameters when it draws a chunk of work: the first 64 bytes of DParams, fetched with ONE
+// sixteen-dword scalar load.  (Read field by field where they are used, every one of them was a scalar load of its own with a
+// wait behind it, a chain of about twenty round trips through the scalar cache per chunk.)
+struct ParamsHot {
+    int spp, spp_shift, width, n_rows, tiles_x; float inv_tiles_x; int n_tiles, wave_resolve, out_format, stripe_count, row0, stripe_shift;
+    uint64_t seed; double inv_spp;
+};
+static_assert(sizeof(ParamsHot) == 64 && offsetof(DParams, inv_spp) == 56 && offsetof(DParams, seed) == 48 && offsetof(DParams, stripe_shift) == 44 &&
+              offsetof(DParams, inv_tiles_x) == 20 && offsetof(DParams, wave_resolve) == 28, "ParamsHot mirrors the head of DParams");
+static __device__ __forceinline__ ParamsHot params_hot() {
+    typedef int i16v __attribute__((ext_vector_type(16)));
+    const i16v raw = *(cptr<i16v>)&kargs()->prm;
+    ParamsHot h;
+    h.spp = raw[0]; h.spp_shift = raw[1]; h.width = raw[2]; h.n_rows = raw[3]; h.tiles_x = raw[4]; h.inv_tiles_x = __builtin_bit_cast(float, (int)raw[5]);
+    h.n_tiles = raw[6]; h.wave_resolve = raw[7]; h.out_format = raw[8]; h.stripe_count = raw[9]; h.row0 = raw[10]; h.stripe_shift = raw[11];
+    h.seed = ((uint64_t)(unsigned)raw[13] << 32) | (uint64_t)(unsigned)raw[12];
+    h.inv_spp = __hiloint2double(raw[15], raw[14]);
+    return h;
+}
 typedef double __attribute__((address_space(3))) *lds_dptr;
 
 DEV V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -1070,8 +1089,7 @@ static __device__ __forceinline__ void trace_body() {
     if (lane == 0) ticket_ahead = atomicAdd(kargs()->ticket + range * 8, (unsigned long long)kChunk);
 
     // this lane's pixel (column, local row) and sample within the chunk the wave holds
-    auto locate = [&](int &px, int &lrow, int &sample) {
-        const auto &prm = kargs()->prm;
+    auto locate = [&](const auto &prm, int &px, int &lrow, int &sample) {
         const unsigned long long item = chunk_item0 + (unsigned)lane;
         // (this ran 518 k times per frame in every lane: shifts and a corrected float reciprocal where the operands allow it)
         const unsigned slot = prm.spp_shift >= 0 ? (unsigned)(item >> prm.spp_shift) : (unsigned)(item / (unsigned)prm.spp);
@@ -1093,11 +1111,12 @@ static __device__ __forceinline__ void trace_body() {
         bool refilled = false;  // (wave-uniform) this round's rays are the primary rays of a chunk just drawn
         qkind = Q_NONE;
         if (__ballot(state != ST_DONE) == 0ull) {  // every lane is done: finish the chunk the wave held, draw the next one
-            const auto &prm = kargs()->prm;
+            const ParamsHot prm = params_hot();
+            const auto &prm_rest = kargs()->prm;
             if (chunk_pending) {
                 if (prm.wave_resolve && item_valid) {
                     int px, lrow, sample;
-                    locate(px, lrow, sample);
+                    locate(prm, px, lrow, sample);
                     if (sample == 0) {
                         V3 sum = mk(0, 0, 0);
                         auto at = [&](int k) { return mk(cx[CX_A * TRACE_BLOCK + k], cx[(CX_A + 1) * TRACE_BLOCK + k], cx[(CX_A + 2) * TRACE_BLOCK + k]); };
@@ -1111,8 +1130,8 @@ static __device__ __forceinline__ void trace_body() {
                     }
                 }
                 // how long the chunk took, for the next frame's work order (costs are >= 0: their bit patterns order like the values)
-                if (prm.tile_cost != nullptr && lane == 0)
-                    atomicMax((unsigned *)(prm.tile_cost + chunk_tile), __float_as_uint((float)(__builtin_amdgcn_s_memrealtime() - chunk_t0)));
+                if (prm_rest.tile_cost != nullptr && lane == 0)
+                    atomicMax((unsigned *)(prm_rest.tile_cost + chunk_tile), __float_as_uint((float)(__builtin_amdgcn_s_memrealtime() - chunk_t0)));
                 chunk_pending = false;
                 item_valid = false;
             }
@@ -1139,9 +1158,9 @@ static __device__ __forceinline__ void trace_body() {
                 // a chunk (64 consecutive items, 64-aligned) never straddles tiles: its tile is wave-uniform and comes
                 // through the scalar cache, in the order the previous frame measured, slowest first (rayhs_order_tiles)
                 const unsigned tslot = prm.spp_shift >= 0 ? (unsigned)(chunk_item0 >> (prm.spp_shift + 6)) : (unsigned)(chunk_item0 / ((unsigned long long)prm.spp * 64ull));
-                const int entry = prm.tile_order ? as_const(prm.tile_order)[tslot] : (int)tslot;
+                const int entry = prm_rest.tile_order ? as_const(prm_rest.tile_order)[tslot] : (int)tslot;
                 chunk_tile = entry & kTileMask;
-                if (prm.tile_cost != nullptr) {
+                if (prm_rest.tile_cost != nullptr) {
                     chunk_t0 = __builtin_amdgcn_s_memrealtime();
                     // the slower the tile was last time, the higher this wave's issue priority while it works on it: a
                     // chunk is a chain of dependent queries, and when a frame is small (one GPU's share of eight) the
@@ -1158,7 +1177,7 @@ static __device__ __forceinline__ void trace_body() {
                 if (cnt.c[6] == 0) cnt.c[6] = 1;  // waves that obtained any work
 #endif
                 int px, lrow, sample;
-                locate(px, lrow, sample);
+                locate(prm, px, lrow, sample);
                 item_valid = px < prm.width && lrow < prm.n_rows;
                 chunk_pending = true;
                 // Every lane of a fresh chunk starts its sample here and now (a lane only ever starts one right after a refill):
@@ -1167,13 +1186,13 @@ static __device__ __forceinline__ void trace_body() {
                     // pixelCoord (src/Image.hs:31-32) + optional sample offset (src/RayHs.hs:178-188)
                     int yrow;
                     // local row -> image row (stripe interleave, include/rayhs.h)
-                    if (prm.stripe_count == 1 && prm.stripe_map == nullptr) yrow = prm.row0 + lrow;
+                    if (prm.stripe_count == 1 && prm_rest.stripe_map == nullptr) yrow = prm.row0 + lrow;
                     else {
-                        const int s_local = prm.stripe_shift >= 0 ? lrow >> prm.stripe_shift : lrow / prm.stripe_rows;
-                        const int in_stripe = lrow - s_local * prm.stripe_rows;
+                        const int s_local = prm.stripe_shift >= 0 ? lrow >> prm.stripe_shift : lrow / prm_rest.stripe_rows;
+                        const int in_stripe = lrow - s_local * prm_rest.stripe_rows;
                         // round-robin ownership, or an explicit list of this device's stripes (rayhs_multi: cost-balanced)
-                        const int s_global = prm.stripe_map ? prm.stripe_map[s_local] : s_local * prm.stripe_count + prm.stripe_rank;
-                        yrow = prm.row0 + s_global * prm.stripe_rows + in_stripe;
+                        const int s_global = prm_rest.stripe_map ? prm_rest.stripe_map[s_local] : s_local * prm.stripe_count + prm_rest.stripe_rank;
+                        yrow = prm.row0 + s_global * prm_rest.stripe_rows + in_stripe;
                     }
                     double fx = (double)px, fy = (double)yrow;
                     if (prm.spp > 1) {
@@ -1418,7 +1437,7 @@ static __device__ __forceinline__ void trace_body() {
                             if (changed) cx_store3(cx, CX_A, result);  // waits in the A slot for the in-wave resolve
                         } else {
                             int px, lrow, sample;
-                            locate(px, lrow, sample);
+                            locate(prm, px, lrow, sample);
                             const size_t pix = (size_t)lrow * (size_t)prm.width + (size_t)px;
                             if (prm.spp > 1) {
                                 // one sample of distributedTracePixel (src/RayHs.hs:173-183); rayhs_resolve folds them in order
