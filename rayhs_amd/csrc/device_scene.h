@@ -8,6 +8,7 @@
 // would derive.  Only the culling boxes of the fast traversal structure are
 // fp32 (conservative, see bvh_build.cpp): they never enter a result.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace rayhs {
@@ -151,12 +152,15 @@ struct DParams {
     int32_t ctx_slots;                // per-lane LDS context doubles: CTX_SLOTS, or CTX_SLOTS + 3 (light term too) when it fits
     int32_t frame_stride;             // threads in the grid (workspace stride)
     int32_t flags_dev;                // development switches of the helper kernels (bit 0: rayhs_static_costs emits its raw feature); bit 1: RAYHS_FLAG_POW5_SQMUL
+    // ---- the last 32 bytes are pointers a chunk refill reads; the trace kernel's argument block continues with four more
+    // (KArgs in trace_kernel.hip: out, counters, ticket, frames), and the eight come with one scalar load
     double *sbuf;                     // spp > 1: per-sample radiance, 3 doubles per (pixel, sample)
     const int32_t *tile_order;        // work order of the 8x8 tiles, slowest first (NULL: scan order); from the previous frame's tile_cost
     const int32_t *stripe_map;        // NULL: round-robin stripes (stripe_rank / stripe_count); else the global stripe index of every
                                       // local stripe of this launch, ascending (rayhs_multi: cost-balanced ownership)
     float *tile_cost;                 // per tile: longest time (100 MHz ticks) one of its chunks took in THIS frame (NULL: not recorded)
 };
+static_assert(sizeof(DParams) % 8 == 0 && offsetof(DParams, sbuf) + 32 == sizeof(DParams), "DParams ends with its four pointers");
 
 // counters[] slots
 enum { CNT_PRIMARY = 0, CNT_REFLECT, CNT_REFRACT, CNT_REFRACT_EXIT, CNT_SHADOW, CNT_NODES, CNT_TRIS,

@@ -109,6 +109,19 @@ struct ParamsHot {
 };
 static_assert(sizeof(ParamsHot) == 64 && offsetof(DParams, inv_spp) == 56 && offsetof(DParams, seed) == 48 && offsetof(DParams, stripe_shift) == 44 &&
               offsetof(DParams, inv_tiles_x) == 20 && offsetof(DParams, wave_resolve) == 28, "ParamsHot mirrors the head of DParams");
+// ... and the pointers it follows: the tail of DParams and the four pointers behind it in KArgs, 64 bytes, one load
+struct PointersHot { double *sbuf; const int32_t *tile_order, *stripe_map; float *tile_cost; void *out; unsigned long long *counters, *ticket; double *frames; };
+static_assert(sizeof(PointersHot) == 64 && offsetof(KArgs, out) == offsetof(KArgs, prm) + sizeof(DParams) && offsetof(KArgs, frames) == offsetof(KArgs, out) + 24,
+              "PointersHot mirrors the tail of DParams and the pointers behind it");
+static __device__ __forceinline__ PointersHot pointers_hot() {
+    typedef int i16v __attribute__((ext_vector_type(16)));
+    const i16v raw = *(cptr<i16v>)&kargs()->prm.sbuf;
+    auto ptr = [&](int k) { return ((unsigned long long)(unsigned)raw[2 * k + 1] << 32) | (unsigned long long)(unsigned)raw[2 * k]; };
+    PointersHot h;
+    h.sbuf = (double *)ptr(0); h.tile_order = (const int32_t *)ptr(1); h.stripe_map = (const int32_t *)ptr(2); h.tile_cost = (float *)ptr(3);
+    h.out = (void *)ptr(4); h.counters = (unsigned long long *)ptr(5); h.ticket = (unsigned long long *)ptr(6); h.frames = (double *)ptr(7);
+    return h;
+}
 static __device__ __forceinline__ ParamsHot params_hot() {
     typedef int i16v __attribute__((ext_vector_type(16)));
     const i16v raw = *(cptr<i16v>)&kargs()->prm;
@@ -1112,6 +1125,7 @@ static __device__ __forceinline__ void trace_body() {
         qkind = Q_NONE;
         if (__ballot(state != ST_DONE) == 0ull) {  // every lane is done: finish the chunk the wave held, draw the next one
             const ParamsHot prm = params_hot();
+            const PointersHot ptrs = pointers_hot();
             const auto &prm_rest = kargs()->prm;
             if (chunk_pending) {
                 if (prm.wave_resolve && item_valid) {
@@ -1126,18 +1140,18 @@ static __device__ __forceinline__ void trace_body() {
                             sum = add(add(add(add(sum, a), b), c), d);
                         }
                         for (; k < prm.spp; k++) sum = add(sum, at(k));
-                        store_pixel(kargs()->out, prm.out_format, (size_t)lrow * (size_t)prm.width + (size_t)px, scl(prm.inv_spp, sum));
+                        store_pixel(ptrs.out, prm.out_format, (size_t)lrow * (size_t)prm.width + (size_t)px, scl(prm.inv_spp, sum));
                     }
                 }
                 // how long the chunk took, for the next frame's work order (costs are >= 0: their bit patterns order like the values)
-                if (prm_rest.tile_cost != nullptr && lane == 0)
-                    atomicMax((unsigned *)(prm_rest.tile_cost + chunk_tile), __float_as_uint((float)(__builtin_amdgcn_s_memrealtime() - chunk_t0)));
+                if (ptrs.tile_cost != nullptr && lane == 0)
+                    atomicMax((unsigned *)(ptrs.tile_cost + chunk_tile), __float_as_uint((float)(__builtin_amdgcn_s_memrealtime() - chunk_t0)));
                 chunk_pending = false;
                 item_valid = false;
             }
             if (exhausted) break;
             {
-                unsigned long long *const ticket = kargs()->ticket;
+                unsigned long long *const ticket = ptrs.ticket;
                 const unsigned long long total_items = (unsigned long long)prm.n_tiles * 64ull * (unsigned long long)prm.spp;
                 const unsigned long long per_range = ((total_items + (unsigned long long)kRanges * kChunk - 1) / ((unsigned long long)kRanges * kChunk)) * kChunk;
                 // the ticket for this chunk was requested one refill ago; the next one is requested below, so that
@@ -1158,9 +1172,9 @@ static __device__ __forceinline__ void trace_body() {
                 // a chunk (64 consecutive items, 64-aligned) never straddles tiles: its tile is wave-uniform and comes
                 // through the scalar cache, in the order the previous frame measured, slowest first (rayhs_order_tiles)
                 const unsigned tslot = prm.spp_shift >= 0 ? (unsigned)(chunk_item0 >> (prm.spp_shift + 6)) : (unsigned)(chunk_item0 / ((unsigned long long)prm.spp * 64ull));
-                const int entry = prm_rest.tile_order ? as_const(prm_rest.tile_order)[tslot] : (int)tslot;
+                const int entry = ptrs.tile_order ? as_const(ptrs.tile_order)[tslot] : (int)tslot;
                 chunk_tile = entry & kTileMask;
-                if (prm_rest.tile_cost != nullptr) {
+                if (ptrs.tile_cost != nullptr) {
                     chunk_t0 = __builtin_amdgcn_s_memrealtime();
                     // the slower the tile was last time, the higher this wave's issue priority while it works on it: a
                     // chunk is a chain of dependent queries, and when a frame is small (one GPU's share of eight) the
@@ -1186,12 +1200,12 @@ static __device__ __forceinline__ void trace_body() {
                     // pixelCoord (src/Image.hs:31-32) + optional sample offset (src/RayHs.hs:178-188)
                     int yrow;
                     // local row -> image row (stripe interleave, include/rayhs.h)
-                    if (prm.stripe_count == 1 && prm_rest.stripe_map == nullptr) yrow = prm.row0 + lrow;
+                    if (prm.stripe_count == 1 && ptrs.stripe_map == nullptr) yrow = prm.row0 + lrow;
                     else {
                         const int s_local = prm.stripe_shift >= 0 ? lrow >> prm.stripe_shift : lrow / prm_rest.stripe_rows;
                         const int in_stripe = lrow - s_local * prm_rest.stripe_rows;
                         // round-robin ownership, or an explicit list of this device's stripes (rayhs_multi: cost-balanced)
-                        const int s_global = prm_rest.stripe_map ? prm_rest.stripe_map[s_local] : s_local * prm.stripe_count + prm_rest.stripe_rank;
+                        const int s_global = ptrs.stripe_map ? ptrs.stripe_map[s_local] : s_local * prm.stripe_count + prm_rest.stripe_rank;
                         yrow = prm.row0 + s_global * prm_rest.stripe_rows + in_stripe;
                     }
                     double fx = (double)px, fy = (double)yrow;
