@@ -96,24 +96,32 @@ struct DLight {   // src/Light.hs:8-10
 };
 
 struct DScene {
-    const DNode *nodes;        // reference tree
-    const DTri *tris;          // reference order
-    const DTriAttr *attrs;     // reference order
-    const FNode *fnodes;       // fast BVH
-    const DTri *ftris;         // BVH leaf order
-    const DTriAttr *fattrs;    // BVH leaf order
+    // ---- the first 64 bytes are what every scene query reads: the trace kernel fetches them at the top of begin() with one
+    // scalar load (by dword index: keep this order)
     const DPlane *planes;
     const DSphere *spheres;
-    const DMesh *meshes;
-    const DObject *objects;
-    const DLight *lights;
-    const double *texels;
-    int32_t n_planes, n_spheres, n_meshes, n_objects, n_lights, n_nodes, n_tris, n_fnodes;
+    int32_t n_planes, n_spheres;
+    int32_t sphere_occluders;  // spheres that can occlude (not Emmit): with none, a round of shadow queries skips the sphere loop
+    int32_t n_lights;
     // planes are stored grouped: [0, plane_axis_end[0]) have a normal along x, [.., [1]) along y, [.., [2]) along z, the
     // rest are in general position (the query loop runs a body specialised per group; ties go by object index)
     int32_t plane_axis_end[3];
-    int32_t sphere_occluders;  // spheres that can occlude (not Emmit): with none, a round of shadow queries skips the sphere loop
+    int32_t n_meshes;
+    const DMesh *meshes;
+    const FNode *fnodes;       // fast BVH
+    const DTri *ftris;         // BVH leaf order
+    // ---- the rest
+    const DTriAttr *fattrs;    // BVH leaf order
+    const DNode *nodes;        // reference tree
+    const DTri *tris;          // reference order
+    const DTriAttr *attrs;     // reference order
+    const DObject *objects;
+    const DLight *lights;
+    const double *texels;
+    int32_t n_objects, n_nodes, n_tris, n_fnodes;
 };
+static_assert(offsetof(DScene, n_planes) == 16 && offsetof(DScene, plane_axis_end) == 32 && offsetof(DScene, n_meshes) == 44 && offsetof(DScene, meshes) == 48 &&
+              offsetof(DScene, ftris) == 64, "the head of DScene is read as two fixed blocks");
 
 // Camera constants of rayFromPixel / unproject / lookAt (src/Projection.hs:22-46,
 // src/Mat.hs:89-93), evaluated on the host once per call (the reference

@@ -580,10 +580,14 @@ struct Tracer {
             k = o_floor > k ? o_floor : k;  // (a NaN k stays NaN)
             beyond_k = (active && shadow && point_light && a >= 0.99) ? k : __builtin_inf();  // (per lane: other lanes never pass)
         }
-        const int n_planes = SC.n_planes, n_spheres = SC.n_spheres, n_meshes = SC.n_meshes;
+        // (the scene's head -- counts, plane groups, the plane and sphere tables -- in ONE sixteen-dword scalar load: field by field
+        // these were eight loads, several of them alone in front of a branch that needs their value)
+        typedef int i16v __attribute__((ext_vector_type(16)));
+        const i16v head = *(cptr<i16v>)&kargs()->sc;
+        const int n_planes = head[4], n_spheres = head[5], sphere_occluders = head[6], n_meshes = head[11];
         // |o| + |d| component by component: below 1e30 every component is finite and small enough for the fp32 boxes
         const double magnitude = ((((fabs(r.o.x) + fabs(r.o.y)) + fabs(r.o.z)) + fabs(r.d.x)) + fabs(r.d.y)) + fabs(r.d.z);
-        const auto planes = as_const(SC.planes);
+        const auto planes = (cptr<DPlane>)(((unsigned long long)(unsigned)head[1] << 32) | (unsigned long long)(unsigned)head[0]);
         // lanes that consider a plane: the closest-hit queries, and the shadow queries still open unless the plane is Emmit
         const mask_t m_closest = EXH ? m_active : (m_active & ~m_shadow);
         mask_t m_shadow_open = EXH ? 0ull : (m_active & m_shadow);  // (shrinks as occluders are found)
@@ -640,15 +644,15 @@ struct Tracer {
         if (m_active != 0ull) {
             // a ray with a non-finite component (0 * inf = NaN in the reference's sums) forces the general form on everyone
             const bool all_finite = __ballot(active && !(magnitude < 1e30)) == 0ull;
-            const int ex = all_finite ? SC.plane_axis_end[0] : 0, ey = all_finite ? SC.plane_axis_end[1] : 0, ez = all_finite ? SC.plane_axis_end[2] : 0;
+            const int ex = all_finite ? head[8] : 0, ey = all_finite ? head[9] : 0, ez = all_finite ? head[10] : 0;
             plane_range(std::integral_constant<int, 0>(), 0, ex);
             plane_range(std::integral_constant<int, 1>(), ex, ey);
             plane_range(std::integral_constant<int, 2>(), ey, ez);
             plane_range(std::integral_constant<int, 3>(), ez, n_planes);
         }
-        const auto spheres = as_const(SC.spheres);
+        const auto spheres = (cptr<DSphere>)(((unsigned long long)(unsigned)head[3] << 32) | (unsigned long long)(unsigned)head[2]);
         // (a round of shadow queries skips the loop when no sphere can occlude: light bulbs are Emmit)
-        const mask_t m_sphere_lanes = (EXH || SC.sphere_occluders != 0) ? m_active : m_closest;
+        const mask_t m_sphere_lanes = (EXH || sphere_occluders != 0) ? m_active : m_closest;
         for (int i = 0; i < n_spheres && m_sphere_lanes != 0ull; i++) {
             // (one batch of scalar loads per sphere, as for the planes)
             struct { double c[3], r2; int obj, occluder; } s;
@@ -782,6 +786,8 @@ struct Tracer {
         Walk w;
         w.stop_traversal();
         w.t_ax = w.t_ay = w.t_az = w.t_bx = w.t_by = w.t_bz = w.t_enter = 0;
+        // (read field by field: one eight-dword load of bytes [40, 72) of the scene record was measured 2 % SLOWER here,
+        // profiles/r04/experiments/scene_head_blocks.log)
         const int n_meshes = SC.n_meshes;
         const auto meshes = as_const(SC.meshes);
         const FNode *const fnodes = SC.fnodes;
