@@ -1026,6 +1026,11 @@ struct Tracer {
     }
 };
 
+// The two triangle tables (BVH order, reference order) as scalar values; which one a lane reads is then a select between two SGPR
+// pairs.  (Written as `bref ? SC.tris : SC.ftris` the compiler selected between the two kernarg ADDRESSES per lane and loaded
+// the pointer itself through the vector memory path: one more dependent memory round trip in front of every triangle hit.)
+template <class T> DEV const T *scalar_value(const T *p) { asm volatile("" : "+s"(p)); return p; }
+
 // ---- global per-lane workspace: LANE_SLOTS lane slots, then FRAME_SLOTS per continuation level ----
 enum : int { LS_V = 0, LS_TERM = 3 };
 enum : int { FS_KIND = 0, FS_F = 2, FS_S = 3, FS_K = 4, FS_A = 5, FS_RO = 8, FS_RD = 11 };
@@ -1260,8 +1265,13 @@ static __device__ __forceinline__ void trace_body() {
                     // found by the reference tree (rays with a zero direction component) are rare: the wave asks once whether it holds any.
                     const bool is_tri = tr.btri >= 0;
                     const bool some_ref = EXH || __ballot(is_tri && tr.bref) != 0ull;
-                    const DTri *const t_arr = !some_ref ? SC.ftris : (tr.bref ? SC.tris : SC.ftris);
-                    const DTriAttr *const a_arr = !some_ref ? SC.fattrs : (tr.bref ? SC.attrs : SC.fattrs);
+                    const DTri *t_arr = scalar_value(SC.ftris);
+                    const DTriAttr *a_arr = scalar_value(SC.fattrs);
+                    if (some_ref) {  // (wave-uniform, rare)
+                        const DTri *const t_ref = scalar_value(SC.tris);
+                        const DTriAttr *const a_ref = scalar_value(SC.attrs);
+                        t_arr = tr.bref ? t_ref : t_arr; a_arr = tr.bref ? a_ref : a_arr;
+                    }
                     // (three vectors, not a struct of arrays: that one lived in scratch, every 16-byte piece of the triangle stored
                     // there behind its own wait, the loads one after the other)
                     V3 h_p0 = mk(0, 0, 0), h_e1 = h_p0, h_e2 = h_p0;
@@ -1340,9 +1350,16 @@ static __device__ __forceinline__ void trace_body() {
                     if (tr.btri >= 0) {
                         // (one batch of loads, as in the hit section)
                         const bool some_ref = EXH || __ballot(tr.bref) != 0ull;
-                        const DTri &h_q = rec(!some_ref ? SC.ftris : (tr.bref ? SC.tris : SC.ftris), tr.btri);
+                        const DTri *t_arr = scalar_value(SC.ftris);
+                        const DTriAttr *a_arr = scalar_value(SC.fattrs);
+                        if (some_ref) {
+                            const DTri *const t_ref = scalar_value(SC.tris);
+                            const DTriAttr *const a_ref = scalar_value(SC.attrs);
+                            t_arr = tr.bref ? t_ref : t_arr; a_arr = tr.bref ? a_ref : a_arr;
+                        }
+                        const DTri &h_q = rec(t_arr, tr.btri);
                         const V3 h_p0 = ld3(h_q.p0), h_e1 = ld3(h_q.e1), h_e2 = ld3(h_q.e2);
-                        const DTriAttr &at = rec(!some_ref ? SC.fattrs : (tr.bref ? SC.attrs : SC.fattrs), tr.btri);
+                        const DTriAttr &at = rec(a_arr, tr.btri);
                         const V3 h_n0 = ld3(at.n0), h_n1 = ld3(at.n1), h_n2 = ld3(at.n2);
                         asm volatile("" ::: "memory");
                         double u, v, t_again;
