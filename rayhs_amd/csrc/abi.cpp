@@ -58,7 +58,7 @@ static int set_error(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return set_error(RAYHS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-static constexpr int kTicketSlots = 64;    // uint64 tickets per launch: 8 range counters, each on its own 64-byte line
+static constexpr int kTicketSlots = 72;    // uint64 per launch: 8 range counters, each on its own 64-byte line, then one line of 8 "range is dry" flags
 static constexpr int kTicketRings = 8;    // launches in flight may overlap on different streams
 
 struct rayhs_scene {
@@ -746,6 +746,8 @@ static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, i
     // no measured order yet: the launcher runs the static estimate + ordering in front of the trace kernel
     need_static = !s->order_valid && !std::getenv("RAYHS_NO_STATIC_ORDER");
     if (s->order_valid || need_static) dp.tile_order = s->order_dev;
+    if (const char *e = std::getenv("RAYHS_FREEZE_ORDER_AFTER"))  // development: keep the order the n-th launch of the handle left, stop re-ordering
+        if (s->order_valid && (long long)s->next_ticket > std::atoll(e)) { dp.tile_cost = s->cost_dev; return RAYHS_OK; }  // (times still taken: the kernel does the same work)
     dp.tile_cost = s->cost_dev;
     record = true;
     return RAYHS_OK;
@@ -894,6 +896,13 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
                      ms(tt0, tt1), ms(tt1, tt2), ms(tt2, tt3), ms(tt3, tt4), bytes, ms(tt4, clk::now()));
     }
     HIP_TRY(hipStreamSynchronize(nullptr));
+#if defined(RAYHS_PROFILE_TIME) || defined(RAYHS_WAVE_ENDS)
+    if (const char *path = std::getenv("RAYHS_DUMP_WAVE_ENDS")) {  // development (tools/wave_ends.py): per wave (start, end, last chunk drawn at, chunks), 100 MHz ticks
+        std::vector<unsigned long long> w((size_t)s->cu_count * 16 * 4);  // (4 workgroups of 4 waves per CU)
+        HIP_TRY(hipMemcpy(w.data(), s->frames, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE *f = std::fopen(path, "wb")) { std::fwrite(w.data(), sizeof(unsigned long long), w.size(), f); std::fclose(f); }
+    }
+#endif
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         float ms = 0;

@@ -649,6 +649,11 @@ struct Tracer {
             plane_range(std::integral_constant<int, 1>(), ex, ey);
             plane_range(std::integral_constant<int, 2>(), ey, ez);
             plane_range(std::integral_constant<int, 3>(), ez, n_planes);
+#ifdef RAYHS_PROBE_PLANES2  // development: what the plane loops cost (they are idempotent: run them twice and compare frame times)
+            { int ex2 = ex, ey2 = ey, ez2 = ez; asm volatile("" : "+s"(ex2), "+s"(ey2), "+s"(ez2));
+              plane_range(std::integral_constant<int, 0>(), 0, ex2); plane_range(std::integral_constant<int, 1>(), ex2, ey2);
+              plane_range(std::integral_constant<int, 2>(), ey2, ez2); plane_range(std::integral_constant<int, 3>(), ez2, n_planes); }
+#endif
         }
         const auto spheres = (cptr<DSphere>)(((unsigned long long)(unsigned)head[3] << 32) | (unsigned long long)(unsigned)head[2]);
         // (a round of shadow queries skips the loop when no sphere can occlude: light bulbs are Emmit)
@@ -816,6 +821,13 @@ struct Tracer {
             float hi[3] = {me.fhi[0] + mg, me.fhi[1] + mg, me.fhi[2] + mg};
             float tn_root;
             if (COUNT && __builtin_amdgcn_inverse_ballot_w64(m_want)) cnt.c[CNT_NODES]++;
+#ifdef RAYHS_PROBE_CULL2  // development: what the root cull costs (run twice)
+            { float cx2 = cxo, cy2 = cyo, cz2 = czo; asm volatile("" : "+v"(cx2), "+v"(cy2), "+v"(cz2));
+              const float mg2 = 4.76837158e-7f * fmaxf(fmaxf(fabsf(cx2), fabsf(cy2)), fabsf(cz2));
+              float lo2[3] = {me.flo[0] - mg2, me.flo[1] - mg2, me.flo[2] - mg2}, hi2[3] = {me.fhi[0] + mg2, me.fhi[1] + mg2, me.fhi[2] + mg2};
+              float tn2; mask_t e2 = m_want & fbox_mask(lo2, hi2, cx2, cy2, cz2, ix, iy, iz, f32_up(lim), tn2);
+              asm volatile("" :: "s"(e2), "v"(tn2)); }
+#endif
             const mask_t em = m_want & fbox_mask(lo, hi, cxo, cyo, czo, ix, iy, iz, f32_up(lim), tn_root);  // lanes that enter this mesh
             if (em == 0ull) continue;
             const bool enter = __builtin_amdgcn_inverse_ballot_w64(em);
@@ -1130,6 +1142,8 @@ static __device__ __forceinline__ void trace_body() {
     TIME_DECL;
 #ifdef RAYHS_PROFILE_TIME
     const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime(), mt0_ = __builtin_amdgcn_s_memtime();
+#elif defined(RAYHS_WAVE_ENDS)
+    const unsigned long long wave_t0_ = __builtin_amdgcn_s_memrealtime();
 #endif
     while (true) {
         bool refilled = false;  // (wave-uniform) this round's rays are the primary rays of a chunk just drawn
@@ -1174,6 +1188,26 @@ static __device__ __forceinline__ void trace_body() {
                     const unsigned long long start = (unsigned long long)range * per_range;
                     const unsigned long long size = start >= total_items ? 0ull : (total_items - start < per_range ? total_items - start : per_range);
                     if (c < size) { chunk_item0 = start + c; break; }  // sizes are multiples of 64: the chunk is whole
+                    // This range is dry.  Before walking on to the next one, note the fact in a line of eight "this range is dry"
+                    // flags behind the counters and look at the other seven.  The line is kept per XCD: written and read at
+                    // WORKGROUP scope, i.e. through this XCD's L2 and no further.  A flag only ever goes from 0 to 1 and is set by a
+                    // wave that has seen the range dry, so any view of the line -- however stale -- that shows all eight set means
+                    // the frame is done, and the wave leaves without touching a counter; any other view only costs the walk.
+                    // Per XCD the first waves to run dry walk the ranges (up to eight dependent atomic round trips on lines that
+                    // every wave of the chip is drawing from: ~30 us) and set the flags; the ~500 that finish after them leave at
+                    // once.  The walk behind EVERY wave's last chunk was 13 % of the 0.23 ms Cornell frame (-26 %; dragon_low -3.5 %,
+                    // dragon -0.8 %: profiles/r04/experiments/dry_range_flags.log).  Measured and dropped on the way there: looking at
+                    // the eight COUNTERS instead (thousands of device-scope loads on the very lines the tickets are drawn from: the
+                    // waves still working wait 25-50 us for theirs at the end of a dragon frame, +2 %), flags at device scope (every
+                    // access goes to the memory side, ~10 ns apart per line: +45 % on the Cornell frame), tickets good for four or
+                    // eight chunks (a tile inside the model then runs as one chain: dragon_low +45 %).
+                    {
+                        unsigned long long *const dry_flags = ticket + kRanges * 8;
+                        if (lane == 0) __hip_atomic_store(dry_flags + range, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        unsigned long long flag = 1ull;
+                        if (lane < kRanges && lane != range) flag = __hip_atomic_load(dry_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (__ballot(flag == 0ull) == 0ull) { exhausted = true; break; }
+                    }
                     if (++ranges_done == kRanges) { exhausted = true; break; }
                     range = (range + 1) & (kRanges - 1);
                     if (lane == 0) c = atomicAdd(ticket + range * 8, (unsigned long long)kChunk);
@@ -1190,12 +1224,14 @@ static __device__ __forceinline__ void trace_body() {
                     // the slower the tile was last time, the higher this wave's issue priority while it works on it: a
                     // chunk is a chain of dependent queries, and when a frame is small (one GPU's share of eight) the
                     // longest chain, not the total work, decides when the kernel ends (-7 % on a 1/8 share)
+#ifndef RAYHS_NO_SETPRIO
                     switch ((unsigned)entry >> kTileBits) {
                     case 0: __builtin_amdgcn_s_setprio(0); break;
                     case 1: __builtin_amdgcn_s_setprio(1); break;
                     case 2: __builtin_amdgcn_s_setprio(2); break;
                     default: __builtin_amdgcn_s_setprio(3); break;
                     }
+#endif
                 }
 #ifdef RAYHS_PROFILE_TIME
                 cnt.c[7]++;  // chunks this wave obtained (lane-0 value is reduced)
@@ -1538,7 +1574,16 @@ static __device__ __forceinline__ void trace_body() {
         atomicMax(&counters[5], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
     cnt.c[9] = __builtin_amdgcn_s_memrealtime();           // summed over waves: (latest end - mean end) is the idle tail
+    if (lane == 0) {  // per wave, into the (now idle) workspace: start, end, when its last chunk was drawn, chunks (RAYHS_DUMP_WAVE_ENDS)
+        unsigned long long *const w_ = (unsigned long long *)kargs()->frames + (size_t)(gtid >> 6) * 4;
+        w_[0] = rt0_; w_[1] = cnt.c[9]; w_[2] = chunk_t0; w_[3] = cnt.c[7];
+    }
     (void)mt0_;
+#elif defined(RAYHS_WAVE_ENDS)  // development: the same record from the production kernel (two clock reads and one store per wave)
+    if (lane == 0 && !COUNT) {
+        unsigned long long *const w_ = (unsigned long long *)kargs()->frames + (size_t)(gtid >> 6) * 4;
+        w_[0] = wave_t0_; w_[1] = __builtin_amdgcn_s_memrealtime(); w_[2] = chunk_t0; w_[3] = 1;
+    }
 #endif
 #ifndef RAYHS_PROFILE_TIME
     unsigned long long *const counters = kargs()->counters;
