@@ -55,7 +55,7 @@ def find(pat, start=0):
 marks = [("(unattributed)", 1),
          ("begin(): preamble", find("__device__ void begin(")),
          ("begin(): plane loops", find("auto plane_range = ")),
-         ("begin(): spheres", find("const auto spheres = as_const(SC.spheres);")),
+         ("begin(): spheres", find("const auto spheres = (cptr<DSphere>)")),
          ("begin(): reference-tree hand-off", find("bool occluded = __builtin_amdgcn_inverse_ballot_w64(m_occ);")),
          ("meshes_reference()", find("__device__ __forceinline__ bool meshes_reference(")),
          ("visit() (per-lane node)", find("template <class ND> __device__ __forceinline__ void visit(")),
