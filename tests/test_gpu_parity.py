@@ -867,6 +867,46 @@ def test_random_scenes_many_samples_per_pixel_bit_exact(tmp_path, seed):
             assert st["rays"] == ost["rays"], seed
 
 
+@pytest.mark.parametrize("n_tris", [1, 2, 3, 4])
+def test_meshes_of_one_leaf(tmp_path, n_tris):
+    # a mesh of at most three triangles is ONE leaf of the fast BVH: its root node's second slot is the empty leaf (no
+    # triangles, the first slot's box -- bvh_build.cpp); four triangles make the smallest tree with an inner node
+    verts = [(-0.8, -0.6, 0.4), (0.7, -0.7, 0.9), (0.1, 0.8, 0.6), (0.9, 0.6, 0.2), (-0.6, 0.5, 1.1), (0.0, -0.1, -0.2)]
+    faces = [(1, 2, 3), (2, 4, 3), (1, 3, 5), (6, 2, 1)][:n_tris]
+    obj = tmp_path / "few.obj"
+    obj.write_text("\n".join(["v %r %r %r" % v for v in verts] + ["vn 0 0 -1"] + ["f %d//1 %d//1 %d//1" % f for f in faces]) + "\n")
+    mesh = {"geometry": {"type": "mesh", "fileName": str(obj), "transform": {"type": "translate", "vector": {"x": 0, "y": 0, "z": 0}}},
+            "material": {"type": "plastic", "ior": 1.4, "cd": {"type": "flat", "color": {"r": 0.3, "g": 0.8, "b": 0.5}}}}
+    text = _scene_json([mesh, FLOOR, SPH], [PT, DIR], w=40, h=32, depth=2)
+    got, want, st, ost = _both(text, tmp_path)
+    assert np.array_equal(got, want) and st["rays"] == ost["rays"]
+    prod, _ = rayhs_amd.ray_trace_file(str(tmp_path / "s.json"))
+    assert np.array_equal(prod, want)
+    assert st["tris_tested"] > 0
+
+
+def test_far_away_scene_walks_the_reference_tree(tmp_path):
+    # coordinates beyond 1e30: the fp32 boxes of the fast BVH cannot hold them, every ray takes the reference tree
+    # (trace_kernel.hip, begin(): `magnitude`); the answer must still be the oracle's, bit for bit
+    big = 3.0e31
+    def at(x, y, z): return {"x": big + x, "y": y, "z": z}
+    mesh = {"geometry": {"type": "mesh", "fileName": "data/cube.obj", "transform": {"type": "translate", "vector": at(0.1, -0.2, 1.0)}},
+            "material": {"type": "diffuse", "cd": {"type": "flat", "color": {"r": 0.9, "g": 0.4, "b": 0.2}}}}
+    wall = {"geometry": {"type": "plane", "point": at(0, 0, 3.0), "normal": {"x": 0, "y": 0, "z": -1}, "tangent": {"x": 1, "y": 0, "z": 0}},
+            "material": {"type": "diffuse", "cd": {"type": "flat", "color": {"r": 0.5, "g": 0.5, "b": 0.9}}}}
+    scene = {"width": 24, "height": 16, "maxDepth": 1,
+             "camera": {"position": at(0, 0, -2.0), "target": at(0, 0, 0), "up": {"x": 0, "y": 1, "z": 0},
+                        "projection": {"type": "perspective", "fovy": 0.9, "width": 2, "height": 2, "near": 1}},
+             "scene": {"objects": [mesh, wall], "lights": [dict(DIR), {"type": "point", "position": at(0.3, 0.8, -0.5), "color": {"r": 60, "g": 60, "b": 60}, "radius": 0.2}]}}
+    p = tmp_path / "s.json"
+    p.write_text(json.dumps(scene))
+    want, ost = oracle_image(str(p))
+    for flags in (PRODUCTION, COUNTING):
+        got, st = rayhs_amd.ray_trace_file(str(p), flags=flags)
+        assert _same(got, want), (flags, int((~((got == want) | (np.isnan(got) & np.isnan(want)))).any(axis=2).sum()))
+    assert st["rays"] == ost["rays"]
+
+
 def test_rays_through_mesh_vertices_and_edges(tmp_path):
     # Adversarial for the culling structure and the tie rule: an orthographic camera whose pixel rays pass
     # through the vertices of a triangulated height field to within an ulp (vertices were placed ON the rays),
