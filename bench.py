@@ -454,7 +454,7 @@ def main():
             "config": {"workload": desc, "scene": scene, "width": w, "height": h, "spp": spp, "max_depth": r.max_depth,
                        "frames_in_flight": IN_FLIGHT, "sharding": f"{STRIPE_ROWS}-row stripes interleaved over {world} rank(s), one gather to rank 0",
                        "kernels": "fma" if args.fma else "exact (-ffp-contract=off, bit-identical to the CPU oracle)",
-                       "scheduling": "tiles handed out slowest-first, from the chunk times the previous frame measured (ordering kernel inside every step)"},
+                       "scheduling": "tiles handed out slowest-first, from the chunk times earlier frames measured (ordering kernels behind the first four frames of a view, then behind every fourth: RAYHS_REORDER_EVERY)"},
             "mpixels_per_s": w * h * args.steps / dt / 1e6,
             "rays_per_frame": rays_frame, "reference_rays_per_frame": reference_rays_frame,
             "kernel_ms_rank0": kernel_ms, "first_frame_ms": first_frame_ms,

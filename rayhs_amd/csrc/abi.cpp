@@ -25,12 +25,12 @@ hipError_t launch_trace_fast(int variant, int grid, size_t lds_bytes, hipStream_
                              const DParams &prm, void *out, unsigned long long *counters, unsigned long long *ticket, double *frames);
 hipError_t launch_resolve_fast(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format);
 hipError_t launch_resolve_exact(hipStream_t stream, const double *sbuf, void *out, int n_pixels, int spp, int out_format);
-hipError_t launch_order_tiles_fast(hipStream_t stream, float *cost, int n, int *order, unsigned *aux, unsigned long long *next_ticket, int ticket_slots);
+hipError_t launch_order_tiles_fast(hipStream_t stream, float *cost, int n, int *order, unsigned *aux, unsigned long long *ticket_ring, int first, int count, int rings, int ticket_slots);
 hipError_t launch_scatter_stripes_fast(hipStream_t stream, const void *src, void *dst, const int *stripe_map, int n_rows, int stripe_rows, long long row_bytes);
 hipError_t launch_scatter_stripes_exact(hipStream_t stream, const void *src, void *dst, const int *stripe_map, int n_rows, int stripe_rows, long long row_bytes);
 hipError_t launch_static_costs_fast(hipStream_t stream, const DScene &sc, const DCamera &cam, const DParams &prm, float *cost);
 hipError_t launch_static_costs_exact(hipStream_t stream, const DScene &sc, const DCamera &cam, const DParams &prm, float *cost);
-hipError_t launch_order_tiles_exact(hipStream_t stream, float *cost, int n, int *order, unsigned *aux, unsigned long long *next_ticket, int ticket_slots);
+hipError_t launch_order_tiles_exact(hipStream_t stream, float *cost, int n, int *order, unsigned *aux, unsigned long long *ticket_ring, int first, int count, int rings, int ticket_slots);
 hipError_t launch_trace_exact(int variant, int grid, size_t lds_bytes, hipStream_t stream, const DScene &sc, const DCamera &cam,
                               const DParams &prm, void *out, unsigned long long *counters, unsigned long long *ticket, double *frames);
 hipError_t launch_warmup_exact(hipStream_t stream);
@@ -60,6 +60,7 @@ static int set_error(int code, const char *fmt, ...) {
 
 static constexpr int kTicketSlots = 72;    // uint64 per launch: 8 range counters, each on its own 64-byte line, then one line of 8 "range is dry" flags
 static constexpr int kTicketRings = 8;    // launches in flight may overlap on different streams
+static constexpr int kTicketsAhead = 4;   // launches whose counters one ordering kernel zeroes ahead (< kTicketRings - frames in flight)
 
 struct rayhs_scene {
     int device = 0;
@@ -81,7 +82,8 @@ struct rayhs_scene {
     mutable int32_t *order_dev = nullptr;
     mutable float *cost_dev = nullptr;
     mutable unsigned *order_aux = nullptr;       // the ordering kernels' histogram rows (ORDER_MAX_BLOCKS x 1024)
-    mutable long long ticket_clean_for = -1;     // launch number whose ticket counters the previous launch's ordering kernel has already zeroed
+    mutable long long ticket_clean_lo = 0, ticket_clean_hi = -1;  // launch numbers whose ticket counters an ordering kernel behind an earlier launch has already zeroed
+    mutable long long frames_on_key = 0;         // launches since the frame geometry (order_key) last changed
     mutable size_t order_cap = 0;
     mutable bool order_valid = false;            // order_dev holds an order for order_key
     mutable int order_key[10] = {0};             // frame geometry the order and the costs belong to
@@ -712,9 +714,9 @@ static int ensure_workspace(const rayhs_scene *s, const DParams &dp, hipStream_t
 // the same view in a progressive render or a benchmark, a neighbouring one in an animation.  The first frame of a
 // geometry -- the only one a one-shot `rayhs -oX scene.json` renders -- is ordered by a static estimate instead
 // (rayhs_static_costs: mesh-box tiles first, reflective surfaces next).  Nothing is read back to the host.
-static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, int variant, DParams &dp, hipStream_t st, bool &record, bool &need_static) {
+static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, int variant, DParams &dp, hipStream_t st, bool &record, bool &need_static, bool &reorder) {
     // (dp.stripe_rank / dp.stripe_count carry the stripe list's id / 0 when the launch has an explicit list)
-    dp.tile_order = nullptr; dp.tile_cost = nullptr; record = false; need_static = false;
+    dp.tile_order = nullptr; dp.tile_cost = nullptr; record = false; need_static = false; reorder = false;
 #ifdef RAYHS_PROFILE_TIME
     const bool production = variant != 2;  // the diagnostic build's "counting" kernel is the production kernel with time stamps
 #else
@@ -724,6 +726,7 @@ static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, i
     const int key[10] = {p->width, p->height, p->row0, p->row1, p->stripe_rows, dp.stripe_rank, dp.stripe_count, p->spp, p->max_depth, dp.n_tiles};
     if (std::memcmp(key, s->order_key, sizeof key) != 0) {
         s->order_valid = false;
+        s->frames_on_key = 0;
         if ((size_t)dp.n_tiles > s->order_cap) {
             if (s->order_dev) HIP_TRY(hipFree(s->order_dev));
             if (s->cost_dev) HIP_TRY(hipFree(s->cost_dev));
@@ -750,6 +753,13 @@ static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, i
         if (s->order_valid && (long long)s->next_ticket > std::atoll(e)) { dp.tile_cost = s->cost_dev; return RAYHS_OK; }  // (times still taken: the kernel does the same work)
     dp.tile_cost = s->cost_dev;
     record = true;
+    // The order of a view that does not change settles within a few frames: the first four frames of a geometry re-order
+    // every time, later ones every fourth frame (the chunk times of the frames in between accumulate: the cost of a tile is
+    // the longest chunk seen since the last ordering).  Three frames in four then run without the two ordering kernels
+    // behind them: 15 us + two launch gaps, 10 % of a 0.17 ms Cornell step.  RAYHS_REORDER_EVERY=1: every frame.
+    static const long long every = [] { const char *e = std::getenv("RAYHS_REORDER_EVERY"); long long v = e ? std::atoll(e) : 4; return v < 1 ? 1 : v; }();
+    reorder = s->frames_on_key < 4 || s->frames_on_key % every == 0;
+    s->frames_on_key++;
     return RAYHS_OK;
 }
 
@@ -771,18 +781,18 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
     if (!s->last_done) HIP_TRY(hipEventCreateWithFlags(&s->last_done, hipEventDisableTiming));
     if (s->have_last && s->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, s->last_done, 0));
     if ((rc = ensure_workspace(s, dp, st))) return rc;
-    bool record_costs = false, static_order = false;
-    if ((rc = plan_tile_order(s, p, variant, dp, st, record_costs, static_order))) return rc;
+    bool record_costs = false, static_order = false, reorder = false;
+    if ((rc = plan_tile_order(s, p, variant, dp, st, record_costs, static_order, reorder))) return rc;
     // ticket counters of this launch: zeroed here, unless the ordering kernel behind the previous launch of this handle has
     // already done it (one fill kernel and one launch gap less per frame in a steady-state loop)
     const unsigned launch_no = s->next_ticket++;
     unsigned long long *ticket = s->tickets + (size_t)(launch_no % kTicketRings) * kTicketSlots;
-    unsigned long long *next_ticket = s->tickets + (size_t)((launch_no + 1) % kTicketRings) * kTicketSlots;
-    if (s->ticket_clean_for != (long long)launch_no) HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long) * kTicketSlots, st));
+    if ((long long)launch_no < s->ticket_clean_lo || (long long)launch_no > s->ticket_clean_hi)
+        HIP_TRY(hipMemsetAsync(ticket, 0, sizeof(unsigned long long) * kTicketSlots, st));
     dp.sbuf = dp.spp > 1 && !dp.wave_resolve ? s->sbuf : nullptr;
     if (static_order) {  // first frame of this geometry: static tile classes -> work order (two tiny kernels, ~20 us)
         hipError_t es = exact ? launch_static_costs_exact(st, s->d, dc, dp, s->cost_dev) : launch_static_costs_fast(st, s->d, dc, dp, s->cost_dev);
-        if (es == hipSuccess) es = exact ? launch_order_tiles_exact(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, nullptr, 0) : launch_order_tiles_fast(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, nullptr, 0);
+        if (es == hipSuccess) es = exact ? launch_order_tiles_exact(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, nullptr, 0, 0, 1, 0) : launch_order_tiles_fast(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, nullptr, 0, 0, 1, 0);
         if (es != hipSuccess) return set_error(RAYHS_ERR_HIP, "static tile ordering launch failed: %s", hipGetErrorString(es));
     }
     if (e0) HIP_TRY(hipEventRecord(e0, st));
@@ -822,8 +832,10 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
             std::fclose(f);
         }
     }
-    if (record_costs) {  // this frame's chunk times -> the next frame's tile order
-        e = exact ? launch_order_tiles_exact(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, next_ticket, kTicketSlots) : launch_order_tiles_fast(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, next_ticket, kTicketSlots);
+    if (reorder) {  // the chunk times measured since the last ordering -> the tile order of the frames that follow; the kernel also
+                    // zeroes the ticket counters of the next kTicketsAhead launches of this handle
+        e = exact ? launch_order_tiles_exact(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, s->tickets, (int)((launch_no + 1) % kTicketRings), kTicketsAhead, kTicketRings, kTicketSlots)
+                  : launch_order_tiles_fast(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, s->tickets, (int)((launch_no + 1) % kTicketRings), kTicketsAhead, kTicketRings, kTicketSlots);
         if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "tile ordering launch failed: %s", hipGetErrorString(e));
         s->order_valid = true;
     }
@@ -832,13 +844,15 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
                   : launch_resolve_fast(st, s->sbuf, d_out, dp.n_rows * dp.width, dp.spp, dp.out_format);
         if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "resolve kernel launch failed: %s", hipGetErrorString(e));
     }
-    // (ticket_clean_for promises that the next launch's counters are zeroed by work ORDERED BEHIND last_done: it is set
+    // (ticket_clean_lo..hi promise that those launches' counters are zeroed by work ORDERED BEHIND last_done: they are set
     // only once that event has been recorded, together with the stream it was recorded on, so that an error return in
     // between leaves the next launch to zero its own counters)
-    s->ticket_clean_for = -1;
+    const long long clean_hi_before = s->ticket_clean_hi;
+    s->ticket_clean_hi = -1;
     HIP_TRY(hipEventRecord(s->last_done, st));
     s->last_stream = st; s->have_last = true;
-    if (record_costs) s->ticket_clean_for = (long long)launch_no + 1;
+    if (reorder) { s->ticket_clean_lo = (long long)launch_no + 1; s->ticket_clean_hi = (long long)launch_no + kTicketsAhead; }
+    else s->ticket_clean_hi = clean_hi_before;  // (what an earlier ordering kernel zeroed stays zeroed: this launch used only its own counters)
     return RAYHS_OK;
 }
 

@@ -1662,7 +1662,7 @@ RAYHS_CAT(rayhs_order_hist, RAYHS_KERNEL_SUFFIX)(const float *cost, int n, unsig
 // Every block sums the rows (class totals, and what the blocks before it hold of each class), scans the totals, and
 // puts its own tiles in place; clears the costs it has read and (block 0) the ticket counters of the next launch.
 extern "C" __global__ void __launch_bounds__(1024)
-RAYHS_CAT(rayhs_order_tiles, RAYHS_KERNEL_SUFFIX)(float *cost, int n, int *order, const unsigned *hist, unsigned long long *next_ticket, int ticket_slots) {
+RAYHS_CAT(rayhs_order_tiles, RAYHS_KERNEL_SUFFIX)(float *cost, int n, int *order, const unsigned *hist, unsigned long long *ticket_ring, int first, int count, int rings, int ticket_slots) {
     __shared__ unsigned cls_start[kOrderClasses], mine[kOrderClasses];
     __shared__ int top;
     const int t = threadIdx.x;
@@ -1674,7 +1674,8 @@ RAYHS_CAT(rayhs_order_tiles, RAYHS_KERNEL_SUFFIX)(float *cost, int n, int *order
     }
     cls_start[t] = total;
     if (t == 0) top = kOrderClasses - 1;
-    if (blockIdx.x == 0 && next_ticket != nullptr && t < ticket_slots) next_ticket[t] = 0ull;
+    if (blockIdx.x == 0 && ticket_ring != nullptr && t < ticket_slots)  // the counters of the next `count` launches of the handle (ring slots first, first + 1, ...)
+        for (int k = 0; k < count; k++) ticket_ring[(size_t)((first + k) % rings) * (size_t)ticket_slots + t] = 0ull;
     __syncthreads();
     if (total) atomicMin(&top, t);  // the slowest class that holds a tile
     for (int off = 1; off < kOrderClasses; off <<= 1) {  // inclusive prefix sum (Hillis-Steele)
@@ -1901,12 +1902,12 @@ hipError_t RAYHS_CAT(launch_scatter_stripes, RAYHS_KERNEL_SUFFIX)(hipStream_t st
                        n_rows, stripe_rows, row_bytes, unit);
     return hipGetLastError();
 }
-// aux: kOrderMaxBlocks * 1024 unsigned (one histogram row per block).  next_ticket (may be NULL): `ticket_slots` counters the
-// scatter kernel zeroes for the launch that follows on this stream.
-hipError_t RAYHS_CAT(launch_order_tiles, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, float *cost, int n, int *order, unsigned *aux, unsigned long long *next_ticket, int ticket_slots) {
+// aux: kOrderMaxBlocks * 1024 unsigned (one histogram row per block).  ticket_ring (may be NULL): `ticket_slots` counters per launch, the
+// scatter kernel zeroes for the next `count` launches of the handle (ring slots first, first + 1, ... modulo `rings`).
+hipError_t RAYHS_CAT(launch_order_tiles, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, float *cost, int n, int *order, unsigned *aux, unsigned long long *ticket_ring, int first, int count, int rings, int ticket_slots) {
     const unsigned grid = (unsigned)std::max(1, std::min(ORDER_MAX_BLOCKS, (n + kOrderBlock - 1) / kOrderBlock));
     hipLaunchKernelGGL(RAYHS_CAT(rayhs_order_hist, RAYHS_KERNEL_SUFFIX), dim3(grid), dim3(kOrderBlock), 0, stream, (const float *)cost, n, aux);
-    hipLaunchKernelGGL(RAYHS_CAT(rayhs_order_tiles, RAYHS_KERNEL_SUFFIX), dim3(grid), dim3(kOrderBlock), 0, stream, cost, n, order, (const unsigned *)aux, next_ticket, ticket_slots);
+    hipLaunchKernelGGL(RAYHS_CAT(rayhs_order_tiles, RAYHS_KERNEL_SUFFIX), dim3(grid), dim3(kOrderBlock), 0, stream, cost, n, order, (const unsigned *)aux, ticket_ring, first, count, rings, ticket_slots);
     return hipGetLastError();
 }
 int RAYHS_CAT(occupancy_trace, RAYHS_KERNEL_SUFFIX)(int variant, size_t lds_bytes) {
