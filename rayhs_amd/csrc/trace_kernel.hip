@@ -892,15 +892,16 @@ struct Tracer {
                     const unsigned long long b1 = pbox_mask(nd.b1, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn1);
                     const unsigned long long m0 = b0 & m_live, m1 = b1 & m_live;  // (an absent child is an empty leaf: no triangles to test)
                     if (COUNT) cnt.c[CNT_NODES] += __builtin_amdgcn_inverse_ballot_w64(m_live) ? (c0 != FNODE_EMPTY) + (c1 != FNODE_EMPTY) : 0;
-                    // the child that more of the lanes that hit something would take first: (ca, ma) before (cb, mb).  The choice is
-                    // made by the scalar unit (left to the compiler the comparison of the two population counts went through a
-                    // vector compare and back)
+                    // the child the FIRST lane that meets anything would take first: (ca, ma) before (cb, mb).  One find-first and one
+                    // bit test on the scalar unit.  (The child MOST lanes prefer -- two population counts and a compare, five scalar
+                    // instructions more per visit -- tested 0.13 % fewer boxes and was no faster on the dragon frame, 1 % slower on
+                    // dragon_low: profiles/r04/experiments/child_order_first_lane.log.)
                     const unsigned long long pref0 = m0 & (~m1 | __ballot(tn0 <= tn1));
-                    const int n_pref0 = (int)__popcll(pref0), n_pref1 = (int)__popcll((m0 | m1) & ~pref0);
-                    int ca, cb;
+                    const unsigned long long m_any = m0 | m1;
+                    int ca, cb, lane1;
                     unsigned long long ma, mb;
-                    asm("s_cmp_ge_i32 %8, %9\n\ts_cselect_b32 %0, %4, %5\n\ts_cselect_b32 %1, %5, %4\n\ts_cselect_b64 %2, %6, %7\n\ts_cselect_b64 %3, %7, %6"
-                        : "=&s"(ca), "=&s"(cb), "=&s"(ma), "=&s"(mb) : "s"(c0), "s"(c1), "s"(m0), "s"(m1), "s"(n_pref0), "s"(n_pref1) : "scc");
+                    asm("s_ff1_i32_b64 %4, %9\n\ts_bitcmp1_b64 %10, %4\n\ts_cselect_b32 %0, %5, %6\n\ts_cselect_b32 %1, %6, %5\n\ts_cselect_b64 %2, %7, %8\n\ts_cselect_b64 %3, %8, %7"
+                        : "=&s"(ca), "=&s"(cb), "=&s"(ma), "=&s"(mb), "=&s"(lane1) : "s"(c0), "s"(c1), "s"(m0), "s"(m1), "s"(m_any), "s"(pref0) : "scc");
                     int next = FNODE_NONE;
                     // (a visit specialised for "both children are inner nodes" -- no leaf code, three branches instead of ten -- was
                     // measured and dropped: +4 % on the dragon frame, profiles/r04/experiments/visit_variants.log)
