@@ -17,8 +17,9 @@
 //     Morton order inside 8x8-pixel tiles; a wave draws a chunk of 64 consecutive items from the ticket
 //     counter of its XCD's band of the frame (8 bands, requested one chunk ahead, next band when dry),
 //     works on it in lock-step -- its lanes hold samples of the same few pixels -- and draws the next
-//     one when all 64 are done.  Tiles are handed out slowest-first: by the chunk times the previous
-//     frame of the same geometry measured, or by a static estimate for the first frame
+//     one when all 64 are done; a wave that finds every band dry -- it learns that from a line of eight flags
+//     in its own XCD's L2, not from the counters -- leaves.  Tiles are handed out slowest-first: by the chunk
+//     times earlier frames of the same geometry measured, or by a static estimate for the first frame
 //     (rayhs_static_costs, rayhs_order_tiles).  When spp divides 64 a pixel's samples sit in one chunk
 //     and are folded in sample order (the reference's foldl) inside the wave; any other spp > 1 goes
 //     through a sample buffer and rayhs_resolve.
@@ -39,9 +40,9 @@
 //     tested; the winner is the reference's because every triangle test is the reference's fp64
 //     Moller-Trumbore and ties are resolved by its rule (first triangle in a leaf, right-most leaf,
 //     first scene object).  Where the reference's own fp64 boxes are NOT a conservative cull its
-//     behaviour is replayed: rays with a (near-)zero direction component walk the reference tree
-//     (meshes_reference), near-edge hits are checked against the reference's box path
-//     (reference_path_admits).
+//     behaviour is replayed: rays with a (near-)zero direction component -- and rays with a huge or non-finite
+//     component, which the fp32 boxes cannot hold -- walk the reference tree (meshes_reference), near-edge
+//     hits are checked against the reference's box path (reference_path_admits).
 //   * The exhaustive kernels walk the reference's own tree for every ray (fp64 boxes, both children
 //     always) and visit exactly its node set.
 //   * Everything that enters a result is fp64 like the reference.  Built twice: "exact"
@@ -51,9 +52,12 @@
 //     shading context of a hit (p, n, cd, A and, when LDS has room, the light term) lives in LDS; the
 //     view direction and the continuation frames of suspended irradiance calls in a global workspace
 //     (slot-major so lanes coalesce); kernel arguments are read from the kernarg segment where they
-//     are used instead of being held in SGPRs (KArgs).
+//     are used instead of being held in SGPRs (KArgs) -- the fields a code path reads together as ONE
+//     wide scalar load (ParamsHot, PointersHot, the scene head in begin(), the head of a plane record).
 // Development switches: RAYHS_PROFILE_LOOPS / RAYHS_PROFILE_TIME (diagnostic builds with trip counters
-// or s_memtime stamps, read with RAYHS_DEBUG_COUNTERS=1), RAYHS_NO_PACKET / RAYHS_PACKET_ALWAYS.
+// or s_memtime stamps, read with RAYHS_DEBUG_COUNTERS=1), RAYHS_WAVE_ENDS (per-wave end times from the
+// production kernel, tools/wave_ends.py), RAYHS_PROBE_PLANES2 / RAYHS_PROBE_CULL2 (a section run twice: what
+// it costs), RAYHS_NO_PACKET / RAYHS_PACKET_ALWAYS, RAYHS_NO_SETPRIO.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
