@@ -48,12 +48,12 @@ WORKLOADS = {
 }
 STRIPE_ROWS = 8
 # frames enqueued at a time, each on its own scene handle and stream (see main): two when there is a gather to hide
-# behind the next frame's trace (N > 1), three when a rank's share is an eighth of the frame or less (a share that small ends
-# with most of the chip idle behind its slowest chunks; measured on one GPU, tools/overlap_frames.py, 1/8 share of the
-# 1080p / 16 spp frame: 1.05 ms per frame with one in flight, 0.73 with two, 0.69 with three; 1/4 share: 1.34 / 1.29 / 1.29),
-# one on a single GPU (two buy nothing there and blur a profiler's per-kernel rows)
+# behind the next frame's trace (N > 1), one on a single GPU (two buy nothing there and blur a profiler's per-kernel rows).
+# RAYHS_BENCH_IN_FLIGHT=3 is opt-in: a one-GPU rehearsal of a 1/8 share (tools/overlap_frames.py: 1.05 ms per frame with one in
+# flight, 0.73 with two, 0.69 with three) says it pays at N = 8, but three handles per rank triple the workspace, frame and
+# output allocations and no 8-GPU run has confirmed it yet.
 _WORLD = int(os.environ.get("WORLD_SIZE", "1"))
-IN_FLIGHT = int(os.environ.get("RAYHS_BENCH_IN_FLIGHT", "0")) or (3 if _WORLD >= 8 else 2 if _WORLD > 1 else 1)
+IN_FLIGHT = int(os.environ.get("RAYHS_BENCH_IN_FLIGHT", "0")) or (2 if _WORLD > 1 else 1)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 # issue roof (same guide: 256 CUs x 4 SIMDs, 2400 MHz max clock; one instruction per SIMD-cycle with all wave slots occupied,
 # profiles/r04/micro/issue_rates.txt)
@@ -125,10 +125,13 @@ def profile_counters(workload, kernel_ms):
 def live_instruction_counts(workload, fma):
     """Fallback when no committed profile matches this kernel source: count the trace kernel's instructions NOW, with two
     short rocprofv3 --pmc passes of this very script as child processes (counters in their own runs, nothing else traced;
-    `--pmc-child` keeps the children from doing the same).  Returns the fields the issue roof needs, or None."""
+    `--pmc-child` keeps the children from doing the same).  Each pass gets at most 75 s (a pass takes ~15 s on a warm box, most
+    of it the interpreter and torch coming up).  Returns (fields the issue roof needs, None) or (None, why not)."""
     import csv, glob, shutil, subprocess, tempfile
-    if os.environ.get("RAYHS_BENCH_NO_LIVE_PMC") or not shutil.which("rocprofv3"):
-        return None
+    if os.environ.get("RAYHS_BENCH_NO_LIVE_PMC"):
+        return None, "live counter passes switched off (RAYHS_BENCH_NO_LIVE_PMC)"
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
     passes = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"],
               ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"]]
     vals = {}
@@ -138,9 +141,12 @@ def live_instruction_counts(workload, fma):
             out = os.path.join(tmp, f"p{i}")
             cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--workload", workload,
                    "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-4k", "--pmc-child"] + (["--fma"] if fma else [])
-            r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=75)
+            except subprocess.TimeoutExpired:
+                return None, f"counter pass {i} ({counters[0]}, ...) did not finish within 75 s"
             if r.returncode != 0:
-                return None
+                return None, f"counter pass {i} exited with {r.returncode}: {(r.stderr or '').strip()[-300:]}"
             acc = {}
             for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
@@ -148,16 +154,17 @@ def live_instruction_counts(workload, fma):
                         acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
             for c in counters:
                 if c not in acc:
-                    return None
+                    return None, f"counter pass {i} wrote no row for {c} on the trace kernel"
                 vals[c] = sum(acc[c]) / len(acc[c])
         insts = sum(vals[c] for c in passes[0])
         arith = vals["SQ_INSTS_VALU_ADD_F64"] + vals["SQ_INSTS_VALU_MUL_F64"] + vals["SQ_INSTS_VALU_FMA_F64"]
         trans = vals["SQ_INSTS_VALU_TRANS_F64"]
         return {"insts_per_launch": insts, "issue_slots_per_launch": (insts - arith - trans) + 1.93 * arith + 6.0 * trans,
                 "valu_f64_share_of_insts": (arith + trans) / vals["SQ_INSTS_VALU"], "salu_per_valu": vals["SQ_INSTS_SALU"] / vals["SQ_INSTS_VALU"],
-                "branches_per_valu": vals["SQ_INSTS_BRANCH"] / vals["SQ_INSTS_VALU"], "valu_insts_per_launch": vals["SQ_INSTS_VALU"]}
-    except Exception:
-        return None
+                "branches_per_valu": vals["SQ_INSTS_BRANCH"] / vals["SQ_INSTS_VALU"], "valu_insts_per_launch": vals["SQ_INSTS_VALU"],
+                "valu_f64_arith_per_launch": arith, "valu_f64_trans_per_launch": trans}, None
+    except Exception as e:
+        return None, f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -407,7 +414,9 @@ def main():
         if ctr is None and world == 1 and not args.pmc_child:
             # no committed profile of THIS kernel source: count its instructions now (two short rocprofv3 --pmc child runs);
             # the HBM / cache / wave-life figures, which need five more passes, stay null
-            live = live_instruction_counts(args.workload, args.fma)
+            live, why_not = live_instruction_counts(args.workload, args.fma)
+            if not live:
+                src = {**src, "live_pmc_passes_in_this_run": False, "live_pmc_failure": why_not}
             if live:
                 names = ("traffic", "hbm_traffic_frac", "hbm_read_frac", "hbm_write_bytes", "l2_hit_rate", "valu_busy", "valu_lane_util", "wave_wait_frac",
                          "valu_pipe_frac", "fp64_tflops_issued", "wave_issuing_frac", "wave_waitcnt_frac", "scalar_dcache_hit_rate", "scalar_icache_hit_rate")

@@ -37,7 +37,8 @@ extern "C" {
  * Version 3 changed no struct: it ADDED rayhs_sizeof(), rayhs_device_prepare() and RAYHS_FLAG_POW5_SQMUL, and render
  * calls now fail with RAYHS_ERR_INVALID on flag bits the library does not know (RAYHS_FLAG_ALL) instead of ignoring
  * them -- a version-2 library would have rendered the flat-product reading of x ^ 5 for a caller that asked for the other. */
-#define RAYHS_ABI_VERSION 3
+/* Version 4 changed no struct: it ADDED rayhs_config_reload(), rayhs_scene_capture_tile_order() and rayhs_scene_tile_order(). */
+#define RAYHS_ABI_VERSION 4
 
 typedef enum {
     RAYHS_OK = 0,
@@ -186,6 +187,14 @@ uint32_t rayhs_sizeof(int which);
 /* number of visible HIP devices (0 if none or the runtime is unusable) */
 int rayhs_device_count(void);
 
+/* The library reads its RAYHS_* environment switches ONCE, when it is loaded (never on the launch path): scheduling policy
+ * that cannot change a pixel -- RAYHS_SCAN_ORDER, RAYHS_NO_STATIC_ORDER, RAYHS_REORDER_EVERY=n, RAYHS_NO_WAVE_RESOLVE,
+ * RAYHS_ROUND_ROBIN_STRIPES, RAYHS_LPT_STRIPES, RAYHS_MULTI_PARALLEL_CREATE, RAYHS_MULTI_SERIAL -- and the stderr diagnostics
+ * RAYHS_DEBUG_COUNTERS, RAYHS_DEBUG_TIMING.  A host that changes its environment afterwards calls this to have them read again;
+ * not while another thread is inside the library.  (Development knobs -- stack cap, workgroups per CU, dumps, BVH leaf size --
+ * exist only in builds made with -DRAYHS_DEV_KNOBS.)  ABI version 4. */
+void rayhs_config_reload(void);
+
 /* Optional: bring up the HIP runtime, the context of `device` and the kernels' code object now, e.g. from a second host
  * thread while the first one is still decoding the scene -- the first rayhs_scene_create of a process otherwise spends
  * 0.1-0.2 s doing exactly that ("end to end").  Thread-safe; calling it more than once, or never,
@@ -235,6 +244,16 @@ int rayhs_render_device(const rayhs_scene *scene, const rayhs_camera *camera,
 int rayhs_render_device_events(const rayhs_scene *scene, const rayhs_camera *camera,
                                const rayhs_render_params *params, void *d_out, void *hip_stream,
                                uint64_t *d_counters, void *ev_before_trace, void *ev_after_trace);
+
+/* Diagnostics / tests (ABI version 4): the order in which a frame's 8x8 tiles are handed to the waves -- slowest first, from
+ * the chunk times earlier frames measured or, for the first frame of a geometry, from a static estimate.
+ * Scheduling only: no pixel depends on it.  After rayhs_scene_capture_tile_order(scene, 1) every launch of the handle keeps a
+ * copy of the order it was given (a device-to-device copy in stream order); rayhs_scene_tile_order waits for the last launch,
+ * copies that order into order[0..cap) (tile indices, row-major over the tile grid) and returns the number of tiles, 0 when
+ * the launch ran in scan order (small frames, counting kernels) or nothing was captured; *from_static (may be NULL) = 1 when
+ * the order came from the static estimate.  order = NULL only asks for the count. */
+int rayhs_scene_capture_tile_order(rayhs_scene *scene, int enable);
+int rayhs_scene_tile_order(const rayhs_scene *scene, int32_t *order, int cap, int *from_static);
 
 /* ---- several GPUs of one node, one process -------------------------------
  * What replaces the reference's parallel pixel map (generatePixels over GHC

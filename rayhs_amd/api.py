@@ -138,6 +138,24 @@ class Rendering:
                                                         C.c_void_p(events[0]), C.c_void_p(events[1])))
         return p
 
+    def capture_tile_order(self, enable=True):
+        """Diagnostics: have every launch of this handle keep the work order of the 8x8 tiles it was given."""
+        L.check(L.load().rayhs_scene_capture_tile_order(self._h, 1 if enable else 0))
+
+    def tile_order(self):
+        """(tile indices in the order the last launch handed them out, came-from-the-static-estimate); empty in scan order."""
+        lib = L.load()
+        static = C.c_int(0)
+        n = lib.rayhs_scene_tile_order(self._h, None, 0, C.byref(static))
+        if n < 0:
+            L.check(n)
+        order = np.empty(n, dtype=np.int32)
+        if n:
+            got = lib.rayhs_scene_tile_order(self._h, order.ctypes.data_as(C.POINTER(C.c_int32)), n, C.byref(static))
+            if got < 0:
+                L.check(got)
+        return order, bool(static.value)
+
     def close(self):
         if getattr(self, "_h", None):
             L.load().rayhs_scene_destroy(self._h)

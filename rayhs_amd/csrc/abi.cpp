@@ -58,9 +58,56 @@ static int set_error(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return set_error(RAYHS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-static constexpr int kTicketSlots = 72;    // uint64 per launch: 8 range counters, each on its own 64-byte line, then one line of 8 "range is dry" flags
+// Every RAYHS_* environment switch of the library, read ONCE -- when the library is loaded, and again only when the host asks
+// (rayhs_config_reload, include/rayhs.h).  Nothing on the launch path calls getenv: a 0.17 ms Cornell step used to make about
+// fifteen such calls, and getenv races with any other thread's setenv.  Three groups:
+//   * policy switches a host may legitimately set (scheduling only, never a pixel): scan order, no static first-frame order,
+//     the sample-buffer resolve, stripe ownership, one thread per device at rayhs_multi_create;
+//   * diagnostics that only print (RAYHS_DEBUG_COUNTERS, RAYHS_DEBUG_TIMING);
+//   * development knobs -- some of them UNSAFE (a stack cap below the tree depth overruns the per-lane LDS stack) -- which exist
+//     only in builds made with -DRAYHS_DEV_KNOBS (the experiment builds under build_exp/); the shipped library has none of them.
+struct Config {
+    bool no_wave_resolve = false, scan_order = false, no_static_order = false;
+    bool multi_parallel_create = false, multi_serial_create = false, round_robin_stripes = false, lpt_stripes = false, multi_serial = false;
+    bool debug_counters = false, debug_timing = false;
+    long long reorder_every = 4;
+#ifdef RAYHS_DEV_KNOBS
+    bool term_in_workspace = false, warm_copy = false, warm_launch = false, debug_sync_first = false, dump_raw_feature = false;
+    int stack_cap = 0, blocks_per_cu = 0;
+    long long freeze_order_after = -1;
+    std::string dump_tile_costs, dump_wave_ends;
+#endif
+};
+static Config read_config() {
+    Config c;
+    auto on = [](const char *name) { return std::getenv(name) != nullptr; };
+    c.no_wave_resolve = on("RAYHS_NO_WAVE_RESOLVE"); c.scan_order = on("RAYHS_SCAN_ORDER"); c.no_static_order = on("RAYHS_NO_STATIC_ORDER");
+    c.multi_parallel_create = on("RAYHS_MULTI_PARALLEL_CREATE"); c.multi_serial_create = on("RAYHS_MULTI_SERIAL_CREATE");
+    c.round_robin_stripes = on("RAYHS_ROUND_ROBIN_STRIPES"); c.lpt_stripes = on("RAYHS_LPT_STRIPES"); c.multi_serial = on("RAYHS_MULTI_SERIAL");
+    c.debug_counters = on("RAYHS_DEBUG_COUNTERS"); c.debug_timing = on("RAYHS_DEBUG_TIMING");
+    if (const char *e = std::getenv("RAYHS_REORDER_EVERY")) c.reorder_every = std::max(1LL, std::atoll(e));
+#ifdef RAYHS_DEV_KNOBS
+    c.term_in_workspace = on("RAYHS_TERM_IN_WORKSPACE"); c.warm_copy = on("RAYHS_WARM_COPY"); c.warm_launch = on("RAYHS_WARM_LAUNCH");
+    c.debug_sync_first = on("RAYHS_DEBUG_SYNC_FIRST"); c.dump_raw_feature = on("RAYHS_DUMP_RAW_FEATURE");
+    if (const char *e = std::getenv("RAYHS_STACK_CAP")) c.stack_cap = std::atoi(e);
+    if (const char *e = std::getenv("RAYHS_BLOCKS_PER_CU")) c.blocks_per_cu = std::atoi(e);
+    if (const char *e = std::getenv("RAYHS_FREEZE_ORDER_AFTER")) c.freeze_order_after = std::atoll(e);
+    if (const char *e = std::getenv("RAYHS_DUMP_TILE_COSTS")) c.dump_tile_costs = e;
+    if (const char *e = std::getenv("RAYHS_DUMP_WAVE_ENDS")) c.dump_wave_ends = e;
+#endif
+    return c;
+}
+static Config g_cfg = read_config();
+// Not to be called while another thread is inside the library (it replaces the switches every entry point reads).
+extern "C" void rayhs_config_reload(void) { g_cfg = read_config(); }
+
+// uint64 per launch: 8 range counters, each alone on its own 128-byte L2 line (stride 16), then -- on a 128-byte line of their own --
+// the 8 "range is dry" flags.  (At a 64-byte stride two counters shared an L2 line, and so did the flags, which are read at
+// workgroup scope, with a counter that takes device-scope atomics in the same kernel.)  144 * 8 B = 1152 B = 9 lines per launch.
+static constexpr int kTicketSlots = 8 * TICKET_STRIDE + 16;  // (TICKET_STRIDE: device_scene.h)
 static constexpr int kTicketRings = 8;    // launches in flight may overlap on different streams
 static constexpr int kTicketsAhead = 4;   // launches whose counters one ordering kernel zeroes ahead (< kTicketRings - frames in flight)
+static_assert(kTicketsAhead < kTicketRings, "an ordering kernel must never zero the counters of the launch it runs behind");
 
 struct rayhs_scene {
     int device = 0;
@@ -97,6 +144,11 @@ struct rayhs_scene {
     mutable void *host_out_dev = nullptr;
     mutable size_t host_out_bytes = 0;
     mutable hipEvent_t host_e0 = nullptr, host_e1 = nullptr;
+    // rayhs_scene_capture_tile_order / rayhs_scene_tile_order (tests, diagnostics): the work order the last launch was given
+    bool capture_order = false;
+    mutable int32_t *captured_dev = nullptr;
+    mutable size_t captured_cap = 0;
+    mutable int captured_tiles = 0, captured_static = 0;
 };
 
 extern "C" const char *rayhs_last_error(void) { return g_error.c_str(); }
@@ -118,7 +170,7 @@ extern "C" int rayhs_device_count(void) {
 
 extern "C" int rayhs_device_prepare(int device) {
     using clk = std::chrono::steady_clock;
-    const bool verbose = std::getenv("RAYHS_DEBUG_TIMING") != nullptr;  // development: where a process's HIP start-up goes
+    const bool verbose = g_cfg.debug_timing;  // diagnostics: where a process's HIP start-up goes
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const clk::time_point t0 = clk::now();
     int ndev = rayhs_device_count();                 // the first HIP call of the process: hipInit
@@ -130,10 +182,11 @@ extern "C" int rayhs_device_prepare(int device) {
     // What a process pays once besides hipInit (measured, profiles/r04/cli_startup.md): ~20 ms at its first host -> device copy
     // (the runtime's copy path), ~8 ms at the first copy back, ~20 ms at its first launch.  The occupancy query below resolves
     // this library's kernels in < 1 ms: the 600 KB code object is NOT what start-up waits for.  Paying the copy / launch costs
-    // here instead (RAYHS_WARM_COPY / RAYHS_WARM_LAUNCH) moved them without shortening a one-shot run, so they stay opt-in.
+    // here instead (RAYHS_WARM_COPY / RAYHS_WARM_LAUNCH, development builds only) moved them without shortening a one-shot run.
     const clk::time_point t2 = clk::now();
     double ms_copy1 = 0, ms_copy2 = 0;
-    if (std::getenv("RAYHS_WARM_COPY")) {   // (opt-in: measured, it moves the cost without shortening the run -- profiles/r04/cli_startup.md)
+#ifdef RAYHS_DEV_KNOBS
+    if (g_cfg.warm_copy) {   // (development: measured, it moves the cost without shortening the run -- profiles/r04/cli_startup.md)
         void *q = nullptr; char buf[64] = {0};
         if (hipMalloc(&q, 64) == hipSuccess) {
             (void)hipMemcpy(q, buf, 64, hipMemcpyHostToDevice);
@@ -143,9 +196,12 @@ extern "C" int rayhs_device_prepare(int device) {
             ms_copy1 = ms(t2, c1); ms_copy2 = ms(c1, clk::now());
         }
     }
+#endif
     const clk::time_point t3 = clk::now();
     (void)occupancy_trace_exact(0, 40 * 1024);
-    if (std::getenv("RAYHS_WARM_LAUNCH")) { (void)launch_warmup_exact(nullptr); (void)hipStreamSynchronize(nullptr); }  // (opt-in, as above)
+#ifdef RAYHS_DEV_KNOBS
+    if (g_cfg.warm_launch) { (void)launch_warmup_exact(nullptr); (void)hipStreamSynchronize(nullptr); }  // (development, as above)
+#endif
     const clk::time_point t4 = clk::now();
     if (verbose)
         std::fprintf(stderr, "rayhs_device_prepare(%d): hipInit (first HIP call) %.1f ms, context %.1f ms, first 64-byte copy to the device %.1f ms and back %.1f ms, "
@@ -525,7 +581,7 @@ static int upload_scene(const PackedScene &pk, int device, rayhs_scene **out) {
     if (hipMalloc(&p, sizeof(unsigned long long) * CNT_SLOTS_DEV) != hipSuccess) return fail(set_error(RAYHS_ERR_HIP, "hipMalloc(counters) failed"));
     s->counters = (unsigned long long *)p;
     *out = s;
-    if (std::getenv("RAYHS_DEBUG_TIMING"))
+    if (g_cfg.debug_timing)
         std::fprintf(stderr, "upload_scene: wait for the runtime + device properties %.1f ms, 12 x hipMalloc %.1f ms, 12 x hipMemcpy %.1f ms, all %.1f ms\n",
                      std::chrono::duration<double, std::milli>(tu1 - tu0).count(), g_ms_malloc, g_ms_copy, std::chrono::duration<double, std::milli>(clk::now() - tu0).count());
     return RAYHS_OK;
@@ -542,7 +598,7 @@ extern "C" int rayhs_scene_create(const rayhs_scene_desc *desc, int device, rayh
     if (rc) return rc;
     const clk::time_point t1 = clk::now();
     rc = upload_scene(pk, device, out);
-    if (std::getenv("RAYHS_DEBUG_TIMING"))  // development: (the upload waits for rayhs_device_prepare when that runs on another thread)
+    if (g_cfg.debug_timing)  // diagnostics: (the upload waits for rayhs_device_prepare when that runs on another thread)
         std::fprintf(stderr, "rayhs_scene_create: validate + flatten + BVH %.1f ms, device allocation + upload %.1f ms\n",
                      std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(clk::now() - t1).count());
     return rc;
@@ -560,6 +616,7 @@ extern "C" void rayhs_scene_destroy(rayhs_scene *s) {
     if (s->tickets) (void)hipFree(s->tickets);
     if (s->counters) (void)hipFree(s->counters);
     if (s->host_out_dev) (void)hipFree(s->host_out_dev);
+    if (s->captured_dev) (void)hipFree(s->captured_dev);
     if (s->last_done) (void)hipEventDestroy(s->last_done);
     if (s->host_e0) (void)hipEventDestroy(s->host_e0);
     if (s->host_e1) (void)hipEventDestroy(s->host_e1);
@@ -632,7 +689,7 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     dp.out_format = p->out_format;
     dp.flags_dev = (p->flags & RAYHS_FLAG_POW5_SQMUL) ? 2 : 0;
     // samples of a pixel are folded inside the wave when they all sit in one 64-item chunk (trace_kernel.hip)
-    dp.wave_resolve = (p->spp > 1 && 64 % p->spp == 0 && !std::getenv("RAYHS_NO_WAVE_RESOLVE")) ? 1 : 0;
+    dp.wave_resolve = (p->spp > 1 && 64 % p->spp == 0 && !g_cfg.no_wave_resolve) ? 1 : 0;
     auto log2_exact = [](int v) { int s = 0; while ((1 << s) < v) s++; return (1 << s) == v ? s : -1; };
     dp.spp_shift = log2_exact(p->spp);
     dp.inv_spp = 1.0 / (double)p->spp;
@@ -649,13 +706,19 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     // 1 counting, 2 exhaustive + counting (the reference's tree)
     variant = (p->flags & RAYHS_FLAG_EXHAUSTIVE) ? 2 : (p->flags & RAYHS_FLAG_COUNT) ? 1 : (s->d.n_fnodes < 65536 && s->d.n_nodes < 65536 ? 0 : 3);
     dp.stack_cap = std::max(std::max(s->tree_depth, s->fast_depth) + 2, 4);  // either tree may be walked (trace_kernel.hip)
-    if (const char *e = std::getenv("RAYHS_STACK_CAP")) dp.stack_cap = std::max(4, std::atoi(e));  // development knob (UNSAFE below the tree depth)
+#ifdef RAYHS_DEV_KNOBS
+    if (g_cfg.stack_cap > 0) dp.stack_cap = std::max(4, g_cfg.stack_cap);  // development knob (UNSAFE below the tree depth: exists only in -DRAYHS_DEV_KNOBS builds)
+#endif
     const int entry = exact ? stack_entry_bytes_exact(variant) : stack_entry_bytes_fast(variant);
     // LDS per workgroup: context slots + stack.  160 KiB per CU / 4 workgroups = 40 KiB each; if the stack
     // leaves room, three more context slots keep the light term in LDS instead of the global workspace.
     const size_t stack_bytes = (size_t)dp.stack_cap * TRACE_BLOCK * (size_t)entry;
     dp.ctx_slots = CTX_SLOTS;
-    if ((size_t)(CTX_SLOTS + 3) * TRACE_BLOCK * sizeof(double) + stack_bytes <= 40 * 1024 && !std::getenv("RAYHS_TERM_IN_WORKSPACE")) dp.ctx_slots = CTX_SLOTS + 3;
+    bool term_in_lds = (size_t)(CTX_SLOTS + 3) * TRACE_BLOCK * sizeof(double) + stack_bytes <= 40 * 1024;
+#ifdef RAYHS_DEV_KNOBS
+    if (g_cfg.term_in_workspace) term_in_lds = false;
+#endif
+    if (term_in_lds) dp.ctx_slots = CTX_SLOTS + 3;
     lds = (size_t)dp.ctx_slots * TRACE_BLOCK * sizeof(double) + stack_bytes;
     if (lds > 160 * 1024) return set_error(RAYHS_ERR_UNSUPPORTED, "tree depth %d needs %zu B of LDS per workgroup (limit 160 KiB)", dp.stack_cap - 2, lds);
     // persistent grid: as many workgroups as the chip keeps resident
@@ -663,9 +726,11 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     if (cache[0] != (int)lds || cache[1] <= 0) {
         int per_cu = exact ? occupancy_trace_exact(variant, lds) : occupancy_trace_fast(variant, lds);
         if (per_cu <= 0) return set_error(RAYHS_ERR_HIP, "trace kernel cannot be resident (occupancy query returned %d)", per_cu);
-        if (const char *e = std::getenv("RAYHS_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));  // development knob
+#ifdef RAYHS_DEV_KNOBS
+        if (g_cfg.blocks_per_cu > 0) per_cu = std::max(1, std::min(per_cu, g_cfg.blocks_per_cu));  // development knob
+#endif
         cache[0] = (int)lds; cache[1] = per_cu;
-        if (std::getenv("RAYHS_DEBUG_COUNTERS"))
+        if (g_cfg.debug_counters)
             std::fprintf(stderr, "rayhs launch: variant %d, lds %zu B, %d blocks/CU, stack cap %d (ref depth %d, bvh depth %d)\n", variant, lds, per_cu,
                          dp.stack_cap, s->tree_depth, s->fast_depth);
     }
@@ -722,7 +787,7 @@ static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, i
 #else
     const bool production = variant == 0 || variant == 3;
 #endif
-    if (!production || dp.n_tiles < 512 || std::getenv("RAYHS_SCAN_ORDER")) return RAYHS_OK;
+    if (!production || dp.n_tiles < 512 || g_cfg.scan_order) return RAYHS_OK;
     const int key[10] = {p->width, p->height, p->row0, p->row1, p->stripe_rows, dp.stripe_rank, dp.stripe_count, p->spp, p->max_depth, dp.n_tiles};
     if (std::memcmp(key, s->order_key, sizeof key) != 0) {
         s->order_valid = false;
@@ -747,18 +812,19 @@ static int plan_tile_order(const rayhs_scene *s, const rayhs_render_params *p, i
         std::memcpy(s->order_key, key, sizeof key);
     }
     // no measured order yet: the launcher runs the static estimate + ordering in front of the trace kernel
-    need_static = !s->order_valid && !std::getenv("RAYHS_NO_STATIC_ORDER");
+    need_static = !s->order_valid && !g_cfg.no_static_order;
     if (s->order_valid || need_static) dp.tile_order = s->order_dev;
-    if (const char *e = std::getenv("RAYHS_FREEZE_ORDER_AFTER"))  // development: keep the order the n-th launch of the handle left, stop re-ordering
-        if (s->order_valid && (long long)s->next_ticket > std::atoll(e)) { dp.tile_cost = s->cost_dev; return RAYHS_OK; }  // (times still taken: the kernel does the same work)
+#ifdef RAYHS_DEV_KNOBS
+    if (g_cfg.freeze_order_after >= 0)  // development: keep the order the n-th launch of the handle left, stop re-ordering
+        if (s->order_valid && (long long)s->next_ticket > g_cfg.freeze_order_after) { dp.tile_cost = s->cost_dev; return RAYHS_OK; }  // (times still taken: the kernel does the same work)
+#endif
     dp.tile_cost = s->cost_dev;
     record = true;
     // The order of a view that does not change settles within a few frames: the first four frames of a geometry re-order
     // every time, later ones every fourth frame (the chunk times of the frames in between accumulate: the cost of a tile is
     // the longest chunk seen since the last ordering).  Three frames in four then run without the two ordering kernels
     // behind them: 15 us + two launch gaps, 10 % of a 0.17 ms Cornell step.  RAYHS_REORDER_EVERY=1: every frame.
-    static const long long every = [] { const char *e = std::getenv("RAYHS_REORDER_EVERY"); long long v = e ? std::atoll(e) : 4; return v < 1 ? 1 : v; }();
-    reorder = s->frames_on_key < 4 || s->frames_on_key % every == 0;
+    reorder = s->frames_on_key < 4 || s->frames_on_key % g_cfg.reorder_every == 0;
     s->frames_on_key++;
     return RAYHS_OK;
 }
@@ -795,23 +861,38 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
         if (es == hipSuccess) es = exact ? launch_order_tiles_exact(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, nullptr, 0, 0, 1, 0) : launch_order_tiles_fast(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, nullptr, 0, 0, 1, 0);
         if (es != hipSuccess) return set_error(RAYHS_ERR_HIP, "static tile ordering launch failed: %s", hipGetErrorString(es));
     }
+    if (s->capture_order) {  // rayhs_scene_capture_tile_order: keep the work order THIS frame is given (scan order: nothing to keep)
+        s->captured_tiles = 0; s->captured_static = static_order ? 1 : 0;
+        if (dp.tile_order != nullptr) {
+            if ((size_t)dp.n_tiles > s->captured_cap) {
+                if (s->captured_dev) HIP_TRY(hipFree(s->captured_dev));
+                s->captured_dev = nullptr; s->captured_cap = 0;
+                void *q = nullptr;
+                HIP_TRY(hipMalloc(&q, (size_t)dp.n_tiles * sizeof(int32_t)));
+                s->captured_dev = (int32_t *)q; s->captured_cap = (size_t)dp.n_tiles;
+            }
+            HIP_TRY(hipMemcpyAsync(s->captured_dev, s->order_dev, (size_t)dp.n_tiles * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            s->captured_tiles = dp.n_tiles;
+        }
+    }
     if (e0) HIP_TRY(hipEventRecord(e0, st));
     hipError_t e = exact ? launch_trace_exact(variant, grid, lds, st, s->d, dc, dp, d_out, (unsigned long long *)d_counters, ticket, s->frames)
                          : launch_trace_fast(variant, grid, lds, st, s->d, dc, dp, d_out, (unsigned long long *)d_counters, ticket, s->frames);
     if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "trace kernel launch failed: %s", hipGetErrorString(e));
     if (e1) HIP_TRY(hipEventRecord(e1, st));
-    if (record_costs && std::getenv("RAYHS_DUMP_TILE_COSTS")) {  // development: measured chunk times per tile, then the static estimate
+#ifdef RAYHS_DEV_KNOBS
+    if (record_costs && !g_cfg.dump_tile_costs.empty()) {  // development: measured chunk times per tile, then the static estimate
         std::vector<float> h((size_t)dp.n_tiles);
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h.data(), s->cost_dev, h.size() * sizeof(float), hipMemcpyDeviceToHost));
-        if (FILE *f = std::fopen(std::getenv("RAYHS_DUMP_TILE_COSTS"), "ab")) {
+        if (FILE *f = std::fopen(g_cfg.dump_tile_costs.c_str(), "ab")) {
             int hdr[4] = {dp.n_tiles, dp.tiles_x, dp.spp, 0};
             std::fwrite(hdr, sizeof hdr, 1, f);
             std::fwrite(h.data(), sizeof(float), h.size(), f);
             void *tmp = nullptr;
             HIP_TRY(hipMalloc(&tmp, h.size() * sizeof(float)));
             DParams dpx = dp;
-            dpx.flags_dev = std::getenv("RAYHS_DUMP_RAW_FEATURE") ? 1 : 0;
+            dpx.flags_dev = g_cfg.dump_raw_feature ? 1 : 0;
             hipError_t es = exact ? launch_static_costs_exact(st, s->d, dc, dpx, (float *)tmp) : launch_static_costs_fast(st, s->d, dc, dpx, (float *)tmp);
             (void)es;
             HIP_TRY(hipStreamSynchronize(st));
@@ -821,17 +902,7 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
             std::fclose(f);
         }
     }
-    if (dp.tile_order != nullptr && std::getenv("RAYHS_DUMP_TILE_ORDER")) {  // development / tests: the work order THIS frame was given
-        std::vector<int32_t> h((size_t)dp.n_tiles);
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipMemcpy(h.data(), s->order_dev, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-        if (FILE *f = std::fopen(std::getenv("RAYHS_DUMP_TILE_ORDER"), "ab")) {
-            int hdr[4] = {dp.n_tiles, dp.tiles_x, static_order ? 1 : 0, 0};  // [2]: 1 = static estimate, 0 = measured chunk times
-            std::fwrite(hdr, sizeof hdr, 1, f);
-            std::fwrite(h.data(), sizeof(int32_t), h.size(), f);
-            std::fclose(f);
-        }
-    }
+#endif
     if (reorder) {  // the chunk times measured since the last ordering -> the tile order of the frames that follow; the kernel also
                     // zeroes the ticket counters of the next kTicketsAhead launches of this handle
         e = exact ? launch_order_tiles_exact(st, s->cost_dev, dp.n_tiles, s->order_dev, s->order_aux, s->tickets, (int)((launch_no + 1) % kTicketRings), kTicketsAhead, kTicketRings, kTicketSlots)
@@ -866,6 +937,27 @@ extern "C" int rayhs_render_device_events(const rayhs_scene *s, const rayhs_came
     return launch(s, cam, p, d_out, (hipStream_t)hip_stream, d_counters, (hipEvent_t)ev_before_trace, (hipEvent_t)ev_after_trace);
 }
 
+
+// Diagnostics / tests: the order in which a frame's 8x8 tiles were handed to the waves (scheduling only, never a pixel).
+extern "C" int rayhs_scene_capture_tile_order(rayhs_scene *s, int enable) {
+    if (!s) return set_error(RAYHS_ERR_INVALID, "NULL argument");
+    s->capture_order = enable != 0;
+    if (!enable) s->captured_tiles = 0;
+    return RAYHS_OK;
+}
+extern "C" int rayhs_scene_tile_order(const rayhs_scene *s, int32_t *order, int cap, int *from_static) {
+    if (!s) return set_error(RAYHS_ERR_INVALID, "NULL argument");
+    if (from_static) *from_static = s->captured_static;
+    const int n = s->captured_tiles;
+    if (n == 0 || !order) return n;
+    if (cap < n) return set_error(RAYHS_ERR_INVALID, "order buffer holds %d entries, the captured order has %d", cap, n);
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->have_last) HIP_TRY(hipEventSynchronize(s->last_done));  // the capture copy was enqueued in front of that launch's kernels
+    HIP_TRY(hipMemcpy(order, s->captured_dev, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) order[i] &= (1 << 28) - 1;  // (the entries carry an issue-priority class above bit 28)
+    return n;
+}
+
 extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_render_params *p, void *out_host, rayhs_stats *stats) {
     if (!s || !p || !out_host) return set_error(RAYHS_ERR_INVALID, "NULL argument");
     int rows = rayhs_render_rows(p);
@@ -887,31 +979,33 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
     if (!s->host_e1) HIP_TRY(hipEventCreate(&s->host_e1));
     const bool count = (p->flags & RAYHS_FLAG_COUNT) != 0;
     if (count) HIP_TRY(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * CNT_SLOTS_DEV, nullptr));
-    if (std::getenv("RAYHS_DEBUG_TIMING") && std::getenv("RAYHS_DEBUG_SYNC_FIRST")) {  // development: is anything still pending from the uploads?
+#ifdef RAYHS_DEV_KNOBS
+    if (g_cfg.debug_timing && g_cfg.debug_sync_first) {  // development: is anything still pending from the uploads?
         const clk::time_point q0 = clk::now();
         (void)hipDeviceSynchronize();
         std::fprintf(stderr, "rayhs_render: hipDeviceSynchronize before the launch took %.1f ms\n", std::chrono::duration<double, std::milli>(clk::now() - q0).count());
     }
+#endif
     const clk::time_point tt1 = clk::now();
     int rc = launch(s, cam, p, s->host_out_dev, nullptr, count ? (uint64_t *)s->counters : nullptr, s->host_e0, s->host_e1);
     if (rc) return rc;
     const clk::time_point tt2 = clk::now();
     clk::time_point tt3 = tt2, tt4 = tt2;
-    if (std::getenv("RAYHS_DEBUG_TIMING")) {  // development: when the trace kernel starts and ends, seen from the host
+    if (g_cfg.debug_timing) {  // diagnostics: when the trace kernel starts and ends, seen from the host
         (void)hipEventSynchronize(s->host_e0); tt3 = clk::now();
         (void)hipEventSynchronize(s->host_e1); tt4 = clk::now();
     }
     // the copy is ordered behind the kernels on the NULL stream and blocks the host until the frame is there
     if (bytes) HIP_TRY(hipMemcpy(out_host, s->host_out_dev, bytes, hipMemcpyDeviceToHost));
-    if (std::getenv("RAYHS_DEBUG_TIMING")) {
+    if (g_cfg.debug_timing) {
         auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         std::fprintf(stderr, "rayhs_render: output buffer + events %.1f ms, enqueue (workspace, order buffers, launches) %.1f ms, until the trace kernel starts %.1f ms, "
                              "until it ends %.1f ms, copy of %zu bytes to the host %.1f ms\n",
                      ms(tt0, tt1), ms(tt1, tt2), ms(tt2, tt3), ms(tt3, tt4), bytes, ms(tt4, clk::now()));
     }
     HIP_TRY(hipStreamSynchronize(nullptr));
-#if defined(RAYHS_PROFILE_TIME) || defined(RAYHS_WAVE_ENDS)
-    if (const char *path = std::getenv("RAYHS_DUMP_WAVE_ENDS")) {  // development (tools/wave_ends.py): per wave (start, end, last chunk drawn at, chunks), 100 MHz ticks
+#if defined(RAYHS_DEV_KNOBS) && (defined(RAYHS_PROFILE_TIME) || defined(RAYHS_WAVE_ENDS))
+    if (const char *path = g_cfg.dump_wave_ends.empty() ? nullptr : g_cfg.dump_wave_ends.c_str()) {  // development (tools/wave_ends.py): per wave (start, end, last chunk drawn at, chunks), 100 MHz ticks
         std::vector<unsigned long long> w((size_t)s->cu_count * 16 * 4);  // (4 workgroups of 4 waves per CU)
         HIP_TRY(hipMemcpy(w.data(), s->frames, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         if (FILE *f = std::fopen(path, "wb")) { std::fwrite(w.data(), sizeof(unsigned long long), w.size(), f); std::fclose(f); }
@@ -930,15 +1024,15 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
             stats->nodes_tested = c[CNT_NODES]; stats->tris_tested = c[CNT_TRIS]; stats->prims_tested = c[CNT_PRIMS];
             stats->shadow_skipped = c[CNT_SHADOW_SKIPPED];
             stats->shaded_hits = c[CNT_SHADED]; stats->pixels = c[CNT_PIXELS] / (unsigned long long)std::max(p->spp, 1);  // the kernel counts samples
-            if (std::getenv("RAYHS_DEBUG_COUNTERS"))  // development: raw loop counters of a -DRAYHS_PROFILE_LOOPS build
+            if (g_cfg.debug_counters)  // development: raw loop counters of a -DRAYHS_PROFILE_LOOPS build
                 std::fprintf(stderr, "rayhs adv[0..3] %llu %llu %llu %llu span_ticks %llu latest_end %llu earliest_start %llu counters[6..15]: %llu %llu | %llu %llu | %llu %llu %llu %llu %llu %llu  kernel_ms %.3f\n", c[0], c[1], c[2], c[3], c[5] - ~c[4], c[5], ~c[4], c[6], c[7], c[8], c[9], c[10], c[11], c[12], c[13], c[14], c[15], (double)ms);
-            if (std::getenv("RAYHS_DEBUG_COUNTERS"))  // (active lanes, wave executions) of: rounds, plane tests, plane divisions, sphere tests, hit, light, return sections, triangle tests
+            if (g_cfg.debug_counters)  // (active lanes, wave executions) of: rounds, plane tests, plane divisions, sphere tests, hit, light, return sections, triangle tests
                 std::fprintf(stderr, "rayhs sections[16..31]: %llu %llu | %llu %llu | %llu %llu | %llu %llu | %llu %llu | %llu %llu | %llu %llu | %llu %llu\n", c[16], c[17], c[18], c[19],
                              c[20], c[21], c[22], c[23], c[24], c[25], c[26], c[27], c[28], c[29], c[30], c[31]);
-            if (std::getenv("RAYHS_DEBUG_COUNTERS"))
+            if (g_cfg.debug_counters)
                 std::fprintf(stderr, "rayhs traversal[32..39]: in-traversal %llu %llu | holding-leaf %llu %llu | lane-visits in passes <16 / <32 lanes: %llu %llu | entering %llu %llu\n",
                              c[32], c[33], c[34], c[35], c[36], c[37], c[38], c[39]);
-            if (std::getenv("RAYHS_DEBUG_COUNTERS"))
+            if (g_cfg.debug_counters)
                 std::fprintf(stderr, "rayhs packet[40..43]: packet visits (lanes, waves) %llu %llu | %llu %llu\n", c[40], c[41], c[42], c[43]);
         }
     }
@@ -1043,7 +1137,7 @@ extern "C" int rayhs_multi_create(const rayhs_scene_desc *desc, const int *devic
     // not run on hardware yet (every box this build has had shows one GPU; tests/test_gpu_parity.py has the two-GPU test
     // that will).  A thread that cannot be started must not take the process down through the extern "C" boundary:
     // whatever was started is joined and the remaining devices are brought up on the calling thread.
-    if (n == 1 || !std::getenv("RAYHS_MULTI_PARALLEL_CREATE") || std::getenv("RAYHS_MULTI_SERIAL_CREATE")) {
+    if (n == 1 || !g_cfg.multi_parallel_create || g_cfg.multi_serial_create) {
         for (size_t i = 0; i < n; i++) bring_up(i);
     } else {
         std::vector<std::thread> workers;
@@ -1076,7 +1170,7 @@ static int plan_stripes(rayhs_multi *m, const rayhs_camera *cam, const rayhs_ren
     const size_t n = m->devices.size();
     const int total = p->row1 - p->row0, R = p->stripe_rows, n_stripes = (total + R - 1) / R;
     std::vector<double> stripe_cost((size_t)n_stripes, 1.0);
-    if (n > 1 && total > 0 && !std::getenv("RAYHS_ROUND_ROBIN_STRIPES")) {
+    if (n > 1 && total > 0 && !g_cfg.round_robin_stripes) {
         rayhs_render_params whole = *p;
         whole.stripe_rows = std::max(total, 1); whole.stripe_rank = 0; whole.stripe_count = 1; whole.flags &= RAYHS_FLAG_FMA;
         DCamera dc; DParams dp; int variant, grid; bool exact; size_t lds;
@@ -1119,8 +1213,8 @@ static int plan_stripes(rayhs_multi *m, const rayhs_camera *cam, const rayhs_ren
     std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return stripe_cost[(size_t)a] > stripe_cost[(size_t)b]; });
     std::vector<std::vector<int32_t>> lists(n);
     std::vector<double> load(n, 0.0);
-    bool round_robin = n == 1 || std::getenv("RAYHS_ROUND_ROBIN_STRIPES");
-    if (!round_robin && !std::getenv("RAYHS_LPT_STRIPES")) {
+    bool round_robin = n == 1 || g_cfg.round_robin_stripes;
+    if (!round_robin && !g_cfg.lpt_stripes) {
         std::vector<double> rr(n, 0.0);
         double total_cost = 0;
         for (int k = 0; k < n_stripes; k++) { rr[(size_t)k % n] += stripe_cost[(size_t)k]; total_cost += stripe_cost[(size_t)k]; }
@@ -1225,7 +1319,7 @@ static int multi_render(rayhs_multi *m, const rayhs_camera *cam, const rayhs_ren
         if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "stripe scatter launch failed: %s", hipGetErrorString(e));
         HIP_TRY(hipEventRecord(m->done[i], m->streams[i]));
         // development (tools/stripe_balance.py): one share at a time, so that entries sharing a GPU are timed as if each had its own
-        if (std::getenv("RAYHS_MULTI_SERIAL")) HIP_TRY(hipStreamSynchronize(m->streams[i]));
+        if (g_cfg.multi_serial) HIP_TRY(hipStreamSynchronize(m->streams[i]));
         return RAYHS_OK;
     };
     for (size_t i = 0; i < n; i++) {

@@ -41,17 +41,23 @@ struct Box3 {
 };
 
 constexpr int kBins = 64;  // 16 bins: 1.2 % more box tests on the dragon frame
-static int max_leaf() {  // development knob: RAYHS_BVH_LEAF=1..7; 2..6 measure within 2 % of each other, 3 is the best
+// Leaves of at most 3 triangles (2..6 measure within 2 % of each other, profiles/r04/experiments/bvh_leaf_sweep.txt); SAH splits
+// only while depth + ceil(log2 n) stays below the depth limit, median splits (which halve n) otherwise, so inner nodes never sit
+// deeper than that.  Builds made with -DRAYHS_DEV_KNOBS (build_exp/) can move both: RAYHS_BVH_LEAF=1..7, RAYHS_BVH_DEPTH_LIMIT.
+#ifdef RAYHS_DEV_KNOBS
+static int max_leaf() {
     static int v = [] { const char *e = std::getenv("RAYHS_BVH_LEAF"); int n = e ? std::atoi(e) : 3; return n < 1 ? 1 : n > 7 ? 7 : n; }();
     return v;
 }
-#define kMaxLeaf (max_leaf())
-static int depth_limit() {  // development knob: RAYHS_BVH_DEPTH_LIMIT (default 28)
+static int depth_limit() {
     static int v = [] { const char *e = std::getenv("RAYHS_BVH_DEPTH_LIMIT"); int n = e ? std::atoi(e) : 28; return n < 4 ? 4 : n > 28 ? 28 : n; }();
     return v;
 }
-#define kDepthLimit (depth_limit())  // SAH splits only while depth + ceil(log2 n) stays below this; median splits
-                                 // (which halve n) are used otherwise, so inner nodes never sit deeper than this
+#define kMaxLeaf (max_leaf())
+#define kDepthLimit (depth_limit())
+#else
+constexpr int kMaxLeaf = 3, kDepthLimit = 28;
+#endif
 
 struct Builder {
     const std::vector<Box3> &tb;       // per-triangle bounds

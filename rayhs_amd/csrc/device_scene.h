@@ -180,6 +180,8 @@ enum { CNT_PRIMARY = 0, CNT_REFLECT, CNT_REFRACT, CNT_REFRACT_EXIT, CNT_SHADOW, 
 
 static constexpr int ORDER_MAX_BLOCKS = 64;  // workgroups of the tile-ordering kernels (one 1024-entry histogram row each)
 static constexpr int TRACE_BLOCK = 256;     // threads per workgroup (4 waves)
+static constexpr int TICKET_STRIDE = 16;    // uint64 between the ticket counters of two bands: each alone on a 128-byte L2 line; the line
+                                            // behind the eighth holds the eight "band is dry" flags
 static constexpr int FRAME_SLOTS = 14;      // doubles per continuation frame
 static constexpr int LANE_SLOTS = 6;        // per-lane doubles kept in the global workspace besides frames (view dir, light term)
 #ifndef RAYHS_CTX_SLOTS

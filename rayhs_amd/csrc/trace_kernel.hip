@@ -327,7 +327,11 @@ constexpr bool kProfileTime = false;
 #define LOOP_TICK(slot) do { } while (0)
 #endif
 
-DEV float f32_up(double v) {  // a float >= v, at most three ulps above it (v >= 0 here; only ever a culling limit: 0 stays 0, inf stays inf)
+// A culling limit in fp32: for v >= 0 a float >= v, at most three ulps above it (0 stays 0, inf stays inf).  A NEGATIVE v -- the
+// closest hit so far lies in front of the point where the ray enters the mesh -- is moved further below zero, which is all
+// met() asks of it: any limit < 0 means "nothing in this box can beat the hit already found" (max(tn, 0) <= limit fails).
+// (Subnormal results are not rounded up; a limit that small only ever meets the t >= 1e-6 of a triangle hit.)
+DEV float f32_up(double v) {
     return (float)v * 1.00000024f;
 }
 
@@ -1113,7 +1117,7 @@ static __device__ __forceinline__ void trace_body() {
     unsigned long long chunk_item0 = 0;  // first item of the chunk this wave holds
     bool exhausted = false;
     // XCD-aware work distribution: the item space is cut into 8 contiguous ranges (bands of tiles), each with
-    // its own ticket counter on its own 64-byte line.  A wave starts on the range of the XCD it runs on
+    // its own ticket counter on its own 128-byte L2 line (TICKET_STRIDE).  A wave starts on the range of the XCD it runs on
     // (HW_REG_XCC_ID), so one XCD's L2 mostly sees one part of the frame and of the BVH; when its range is
     // used up it moves on to the next one, so the split only steers locality, never the balance.
     constexpr int kRanges = 8;
@@ -1127,7 +1131,7 @@ static __device__ __forceinline__ void trace_body() {
     unsigned long long chunk_t0 = 0;  // when the current chunk was obtained, and the tile it belongs to (a chunk never straddles tiles)
     int chunk_tile = 0;
     unsigned long long ticket_ahead = 0;  // lane 0: ticket of `range` requested ahead of need
-    if (lane == 0) ticket_ahead = atomicAdd(kargs()->ticket + range * 8, (unsigned long long)kChunk);
+    if (lane == 0) ticket_ahead = atomicAdd(kargs()->ticket + range * TICKET_STRIDE, (unsigned long long)kChunk);
 
     // this lane's pixel (column, local row) and sample within the chunk the wave holds
     auto locate = [&](const auto &prm, int &px, int &lrow, int &sample) {
@@ -1207,7 +1211,7 @@ static __device__ __forceinline__ void trace_body() {
                     // access goes to the memory side, ~10 ns apart per line: +45 % on the Cornell frame), tickets good for four or
                     // eight chunks (a tile inside the model then runs as one chain: dragon_low +45 %).
                     {
-                        unsigned long long *const dry_flags = ticket + kRanges * 8;
+                        unsigned long long *const dry_flags = ticket + kRanges * TICKET_STRIDE;  // (a 128-byte line of their own)
                         if (lane == 0) __hip_atomic_store(dry_flags + range, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         unsigned long long flag = 1ull;
                         if (lane < kRanges && lane != range) flag = __hip_atomic_load(dry_flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1215,10 +1219,10 @@ static __device__ __forceinline__ void trace_body() {
                     }
                     if (++ranges_done == kRanges) { exhausted = true; break; }
                     range = (range + 1) & (kRanges - 1);
-                    if (lane == 0) c = atomicAdd(ticket + range * 8, (unsigned long long)kChunk);
+                    if (lane == 0) c = atomicAdd(ticket + range * TICKET_STRIDE, (unsigned long long)kChunk);
                 }
                 if (exhausted) break;
-                if (lane == 0) ticket_ahead = atomicAdd(ticket + range * 8, (unsigned long long)kChunk);
+                if (lane == 0) ticket_ahead = atomicAdd(ticket + range * TICKET_STRIDE, (unsigned long long)kChunk);
                 // a chunk (64 consecutive items, 64-aligned) never straddles tiles: its tile is wave-uniform and comes
                 // through the scalar cache, in the order the previous frame measured, slowest first (rayhs_order_tiles)
                 const unsigned tslot = prm.spp_shift >= 0 ? (unsigned)(chunk_item0 >> (prm.spp_shift + 6)) : (unsigned)(chunk_item0 / ((unsigned long long)prm.spp * 64ull));

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("rayhs_abi_version", C.c_int, []),
     ("rayhs_sizeof", C.c_uint32, [C.c_int]),
     ("rayhs_device_count", C.c_int, []),
+    ("rayhs_config_reload", None, []),
     ("rayhs_device_prepare", C.c_int, [C.c_int]),
     ("rayhs_scene_create", C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
     ("rayhs_scene_destroy", None, [C.c_void_p]),
@@ -83,6 +84,8 @@ SYMBOLS = [
     ("rayhs_render_device", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rayhs_render_device_events", C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p]),
+    ("rayhs_scene_capture_tile_order", C.c_int, [C.c_void_p, C.c_int]),
+    ("rayhs_scene_tile_order", C.c_int, [C.c_void_p, _pi32, C.c_int, C.POINTER(C.c_int)]),
     ("rayhs_multi_create", C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     ("rayhs_multi_destroy", None, [C.c_void_p]),
     ("rayhs_multi_device_count", C.c_int, [C.c_void_p]),
@@ -103,7 +106,7 @@ SYMBOLS = [
     ("rayhs_sample01", C.c_double, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
 ]
 
-ABI_VERSION = 3   # RAYHS_ABI_VERSION this binding was written against
+ABI_VERSION = 4   # RAYHS_ABI_VERSION this binding was written against
 _LIB = None
 
 
@@ -123,7 +126,7 @@ def load():
                               "(hipcc --offload-arch=gfx950); rayhs_amd has no CPU fallback")
         lib = C.CDLL(LIB_PATH)
         # the structs below are hand-written mirrors: refuse a library of another ABI version or another layout
-        # instead of letting it write past them (version 2 grew rayhs_stats, version 3 added entry points;
+        # instead of letting it write past them (version 2 grew rayhs_stats, versions 3 and 4 added entry points;
         # include/rayhs.h, "ABI history").  The version is asked FIRST: an older library lacks symbols bound below.
         try:
             lib.rayhs_abi_version.restype = C.c_int

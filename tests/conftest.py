@@ -18,6 +18,20 @@ def _repo_cwd(monkeypatch):
     monkeypatch.chdir(ROOT)
 
 
+@pytest.fixture
+def library_env(monkeypatch):
+    """library_env(name, value="1"): set a RAYHS_* switch for one test.  The library reads its environment once, when it is
+    loaded (never on the launch path), so it is told to read it again -- and once more when the test's environment is restored."""
+    from rayhs_amd import lib as L
+
+    def set_(name, value="1"):
+        monkeypatch.setenv(name, value)
+        L.load().rayhs_config_reload()
+    yield set_
+    monkeypatch.undo()
+    L.load().rayhs_config_reload()
+
+
 def pytest_sessionstart(session):
     # the C-ABI library and the oracle are build products (git-ignored); build them if this checkout has none
     lib = os.path.join(ROOT, "rayhs_amd", "bin", "librayhs_hip.so")

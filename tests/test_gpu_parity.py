@@ -102,7 +102,7 @@ def test_bit_exact_against_oracle_at_other_sizes(scene, w, h, spp):
 
 
 @pytest.mark.parametrize("spp", [2, 3, 5, 8, 16, 32, 64, 96])
-def test_sample_fold_is_in_sample_order_for_every_spp(spp, monkeypatch):
+def test_sample_fold_is_in_sample_order_for_every_spp(spp, library_env):
     # spp dividing 64 is folded inside the wave, anything else through the sample buffer + resolve pass;
     # both must equal the reference's foldl over samples (src/RayHs.hs:169-171), with and without counters
     scene = "data/transform.json"
@@ -110,7 +110,7 @@ def test_sample_fold_is_in_sample_order_for_every_spp(spp, monkeypatch):
     for flags in (0, L.FLAG_COUNT):
         got, _ = rayhs_amd.ray_trace_file(scene, width=41, height=29, spp=spp, flags=flags)
         assert np.array_equal(got, want), flags
-    monkeypatch.setenv("RAYHS_NO_WAVE_RESOLVE", "1")  # development knob: force the buffer path
+    library_env("RAYHS_NO_WAVE_RESOLVE")  # policy switch: force the buffer path
     got, _ = rayhs_amd.ray_trace_file(scene, width=41, height=29, spp=spp)
     assert np.array_equal(got, want)
 
@@ -331,9 +331,9 @@ def test_empty_row_selection_records_the_callers_events():
 
 # --------------------------------------- several GPUs from one process (rayhs_multi)
 @pytest.mark.parametrize("policy", ["default", "RAYHS_LPT_STRIPES", "RAYHS_ROUND_ROBIN_STRIPES"])
-def test_multi_device_frame_equals_the_single_device_frame_one_gpu_rehearsal(policy, monkeypatch):
+def test_multi_device_frame_equals_the_single_device_frame_one_gpu_rehearsal(policy, library_env):
     if policy != "default":
-        monkeypatch.setenv(policy, "1")      # development switches: force the cost-sorted / the interleaved ownership
+        library_env(policy)                  # policy switches: force the cost-sorted / the interleaved ownership
     # the N-GPU path of the library (stripe lists balanced by the static estimate, per-device streams, peer push into
     # the frame on the first device) with every "device" being GPU 0 -- what the driver's 8-GPU node runs with 8 GPUs
     rd = RenderDesc("scenes/dragon_low_1080p.json")
@@ -355,14 +355,14 @@ def test_multi_device_frame_equals_the_single_device_frame_one_gpu_rehearsal(pol
 
 @pytest.mark.skipif(L.load().rayhs_device_count() < 2, reason="needs two physical GPUs (peer access, cross-device events)")
 @pytest.mark.parametrize("create", ["serial", "one thread per device"])
-def test_multi_device_on_two_physical_gpus_equals_the_single_device_frame(create, monkeypatch):
+def test_multi_device_on_two_physical_gpus_equals_the_single_device_frame(create, library_env):
     # what the one-GPU rehearsals above cannot execute: hipDeviceEnablePeerAccess, the peer writes of rayhs_scatter_stripes
     # into a frame that lives on devices[0] (the library's own, and a caller-owned d_out), and the cross-device
     # hipStreamWaitEvent on every device's `done` event.  Runs wherever the box shows >= 2 GPUs -- with the devices brought
     # up one after the other (the default) and on one thread each (RAYHS_MULTI_PARALLEL_CREATE, opt-in until this has passed).
     import torch
     if create != "serial":
-        monkeypatch.setenv("RAYHS_MULTI_PARALLEL_CREATE", "1")
+        library_env("RAYHS_MULTI_PARALLEL_CREATE")
     n = min(L.load().rayhs_device_count(), 8)
     rd = RenderDesc("scenes/dragon_low_1080p.json")
     single = Rendering(rd)
@@ -693,7 +693,7 @@ def test_point_light_on_or_next_to_a_wall(tmp_path, offset):
     assert st["rays"] == ost["rays"]
 
 
-def test_feedback_tile_order_never_changes_a_pixel(monkeypatch):
+def test_feedback_tile_order_never_changes_a_pixel(library_env):
     # frame 1 runs in scan order and measures chunk times, frames 2 and 3 are worked slowest-tile-first
     # (rayhs_order_tiles); a frame with the ordering switched off must be the same image, bit for bit
     r = build_rendering("scenes/dragon_low_1080p.json")
@@ -703,13 +703,13 @@ def test_feedback_tile_order_never_changes_a_pixel(monkeypatch):
     assert np.array_equal(band[0], band[1])          # a new geometry starts over in scan order
     rows = tiles.stripe_rows_of(1, 2, 1080, 8, row0=400, row1=720)
     assert np.array_equal(band[0], frames[0][rows])
-    monkeypatch.setenv("RAYHS_SCAN_ORDER", "1")
+    library_env("RAYHS_SCAN_ORDER")
     plain, _ = r.ray_trace(spp=4, out_format=L.OUT_F32)
     assert np.array_equal(plain, frames[0])
     r.close()
 
 
-def test_first_frame_static_order_is_the_same_image_and_close_to_steady_state(monkeypatch):
+def test_first_frame_static_order_is_the_same_image_and_close_to_steady_state(library_env):
     # the first frame of a handle is ordered by rayhs_static_costs (no measured chunk times yet): same pixels as the
     # scan-order frame and as the feedback-ordered frames; its kernel time stays near the steady state (measured:
     # within 6 % on configs[1]..[4], profiles/r02/first_frame.jsonl -- asserted loosely, it is a timing)
@@ -725,7 +725,7 @@ def test_first_frame_static_order_is_the_same_image_and_close_to_steady_state(mo
             if i >= 1:
                 steady.append(st["kernel_ms"])
         r.close()
-    monkeypatch.setenv("RAYHS_NO_STATIC_ORDER", "1")
+    library_env("RAYHS_NO_STATIC_ORDER")
     r = br("scenes/dragon_low_1080p.json")
     scan, _ = r.ray_trace(spp=4, out_format=L.OUT_F32)
     r.close()
@@ -750,24 +750,24 @@ def _leading_tiles(order, share):
     return set(int(t) for t in lead)
 
 
-def test_first_frame_static_order_is_a_permutation_that_leads_with_the_slow_tiles(monkeypatch, tmp_path):
+def test_first_frame_static_order_is_a_permutation_that_leads_with_the_slow_tiles():
     # not a timing: the order the first frame was GIVEN (static estimate -> rayhs_order_hist / rayhs_order_tiles) is read
-    # back and must (a) hold every tile exactly once and (b) start with the tiles the second frame's MEASURED order starts
-    # with -- a broken estimate or ordering kernel degrades to scan order, where that overlap is the share itself (5 %)
-    dump = tmp_path / "order.bin"
-    monkeypatch.setenv("RAYHS_DUMP_TILE_ORDER", str(dump))
+    # back (rayhs_scene_capture_tile_order / rayhs_scene_tile_order) and must (a) hold every tile exactly once and (b) start
+    # with the tiles the second frame's MEASURED order starts with -- a broken estimate or ordering kernel degrades to scan
+    # order, where that overlap is the share itself (5 %)
     r = build_rendering("scenes/dragon_low_1080p.json")
+    r.capture_tile_order(True)
+    recs = []
     for _ in range(2):
         r.ray_trace(spp=4, out_format=L.OUT_F32)
+        recs.append(r.tile_order())
+    assert r.ray_trace(spp=4, flags=COUNTING, row0=0, row1=8)[1]["pixels"] == 1920 * 8 and len(r.tile_order()[0]) == 0  # (a counting run: scan order)
     r.close()
-    raw = np.fromfile(dump, dtype=np.int32)
-    n = int(raw[0])
-    assert n == 240 * 135 and len(raw) == 2 * (4 + n)
-    recs = [(raw[k * (4 + n):k * (4 + n) + 4], raw[k * (4 + n) + 4:(k + 1) * (4 + n)] & 0x0FFFFFFF) for k in range(2)]
-    assert recs[0][0][2] == 1 and recs[1][0][2] == 0          # static estimate first, measured chunk times second
-    for _, order in recs:
-        assert np.array_equal(np.sort(order), np.arange(n))   # a permutation of the tiles
-    static_lead, measured_lead = _leading_tiles(recs[0][1], 0.05), _leading_tiles(recs[1][1], 0.15)
+    n = 240 * 135
+    assert recs[0][1] is True and recs[1][1] is False        # static estimate first, measured chunk times second
+    for order, _ in recs:
+        assert len(order) == n and np.array_equal(np.sort(order), np.arange(n))   # a permutation of the tiles
+    static_lead, measured_lead = _leading_tiles(recs[0][0], 0.05), _leading_tiles(recs[1][0], 0.15)
     overlap = len(static_lead & measured_lead) / len(static_lead)
     assert overlap > 0.5, overlap
 

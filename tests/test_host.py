@@ -29,7 +29,7 @@ def test_library_is_in_tree_and_exports_every_declared_symbol():
     lib = C.CDLL(L.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert L.load().rayhs_abi_version() == 3
+    assert L.load().rayhs_abi_version() == 4
 
 
 def test_header_is_plain_c_and_a_c_client_links(tmp_path):
@@ -44,7 +44,7 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
                          "-L", bindir, "-lrayhs_hip", "-Wl,-rpath," + bindir], capture_output=True, text=True)
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert run.returncode == 0 and run.stdout.split()[0] == "3"
+    assert run.returncode == 0 and run.stdout.split()[0] == "4"
 
 
 def test_struct_sizes_match_the_header():
@@ -64,9 +64,9 @@ def test_loader_refuses_a_library_of_another_abi_version_or_layout(monkeypatch):
     # asks for stats (include/rayhs.h, "ABI history").  The binding checks version and struct sizes when it loads.
     monkeypatch.setattr(L, "_LIB", None)
     monkeypatch.setattr(L, "ABI_VERSION", 1)
-    with pytest.raises(ImportError, match="ABI version 3"):
+    with pytest.raises(ImportError, match="ABI version 4"):
         L.load()
-    monkeypatch.setattr(L, "ABI_VERSION", 3)
+    monkeypatch.setattr(L, "ABI_VERSION", 4)
 
     class Stats88(C.Structure):  # the version-1 layout: no shadow_skipped
         _fields_ = L.Stats._fields_[:-1]
@@ -81,7 +81,7 @@ def test_loader_refuses_a_library_of_another_abi_version_or_layout(monkeypatch):
     with pytest.raises(ImportError, match="does not export rayhs_entry_point_of_a_later_version"):
         L.load()
     monkeypatch.undo()
-    assert L.load().rayhs_abi_version() == 3
+    assert L.load().rayhs_abi_version() == 4
 
 
 def test_sampler_matches_oracle_definition():
