@@ -748,6 +748,9 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
 
 static int ensure_workspace(const rayhs_scene *s, const DParams &dp, hipStream_t st) {
     size_t need = ((size_t)LANE_SLOTS + (size_t)std::max(dp.max_depth, 1) * FRAME_SLOTS) * (size_t)dp.frame_stride * sizeof(double);
+#ifdef RAYHS_PROBE_WS_TWICE
+    need = 2 * ((size_t)LANE_SLOTS + (size_t)std::max(dp.max_depth, 3) * FRAME_SLOTS) * (size_t)dp.frame_stride * sizeof(double);  // (maxDepth <= 3 only)
+#endif
     if (need >= ((size_t)1 << 32) || dp.frame_stride >= (1 << 24))  // 32-bit byte offsets / 24-bit multiplies in the kernel
         return set_error(RAYHS_ERR_INVALID, "max_depth %d needs a %zu-byte continuation workspace; the limit is 4 GiB", dp.max_depth, need);
     if (need > s->frames_bytes) {

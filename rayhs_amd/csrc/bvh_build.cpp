@@ -22,7 +22,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <string>
+#include <vector>
 
 namespace rayhs {
 
@@ -196,6 +199,51 @@ void build_fast_bvh(const double *tri_pos, const std::vector<int> &tri_ids, Fast
     out.depth = bl.max_depth;
     out.nodes.swap(bl.nodes);
     out.order.swap(bl.order);
+#ifdef RAYHS_DEV_KNOBS
+    // development (profiles/r05/experiments/bvh_node_order.log): the builder emits nodes in depth-first order (a node, its left
+    // subtree, its right subtree).  RAYHS_BVH_ORDER = bfs | top<k> | veb<h> re-numbers them: breadth-first throughout; the top k
+    // levels breadth-first and every subtree below depth-first; treelets of h levels, breadth-first inside, recursively.
+    if (const char *mode = std::getenv("RAYHS_BVH_ORDER")) {
+        const int n = (int)out.nodes.size();
+        if (out.root >= 0 && n > 1) {
+            std::vector<int> seq;  // old ids in their new order
+            seq.reserve((size_t)n);
+            auto kids = [&](int id, int *k) { int m = 0; if (out.nodes[(size_t)id].c0 >= 0) k[m++] = out.nodes[(size_t)id].c0; if (out.nodes[(size_t)id].c1 >= 0) k[m++] = out.nodes[(size_t)id].c1; return m; };
+            std::function<void(int)> dfs = [&](int id) { seq.push_back(id); int k[2]; const int m = kids(id, k); for (int i = 0; i < m; i++) dfs(k[i]); };
+            // breadth-first over `levels` levels below `id`; the nodes hanging off the last level are returned in `frontier`
+            auto bfs_levels = [&](int id, int levels, std::vector<int> &frontier) {
+                std::vector<int> cur{id};
+                for (int l = 0; l < levels && !cur.empty(); l++) {
+                    std::vector<int> next;
+                    for (int x : cur) { seq.push_back(x); int k[2]; const int m = kids(x, k); for (int i = 0; i < m; i++) next.push_back(k[i]); }
+                    cur.swap(next);
+                }
+                frontier = cur;
+            };
+            const std::string md = mode;
+            if (md == "bfs") { std::vector<int> f; bfs_levels(out.root, 1 << 30, f); }
+            else if (md.rfind("top", 0) == 0) { std::vector<int> f; bfs_levels(out.root, std::max(1, std::atoi(mode + 3)), f); for (int x : f) dfs(x); }
+            else if (md.rfind("veb", 0) == 0) {
+                const int h = std::max(1, std::atoi(mode + 3));
+                std::function<void(int)> treelet = [&](int id) { std::vector<int> f; bfs_levels(id, h, f); for (int x : f) treelet(x); };
+                treelet(out.root);
+            } else dfs(out.root);
+            if ((int)seq.size() == n) {
+                std::vector<int> fresh((size_t)n);
+                for (int i = 0; i < n; i++) fresh[(size_t)seq[(size_t)i]] = i;
+                std::vector<FNodeBuild> re((size_t)n);
+                for (int i = 0; i < n; i++) {
+                    FNodeBuild nd = out.nodes[(size_t)seq[(size_t)i]];
+                    if (nd.c0 >= 0) nd.c0 = fresh[(size_t)nd.c0];
+                    if (nd.c1 >= 0) nd.c1 = fresh[(size_t)nd.c1];
+                    re[(size_t)i] = nd;
+                }
+                out.nodes.swap(re);
+                out.root = fresh[(size_t)out.root];
+            }
+        }
+    }
+#endif
 }
 
 }  // namespace rayhs

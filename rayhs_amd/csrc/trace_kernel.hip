@@ -919,7 +919,9 @@ struct Tracer {
                         if (m_side == 0ull) continue;
                         if (c >= 0) {  // inner child: walk it next, or after the first one
                             if (next == FNODE_NONE) next = c;
-                            else { wstack[sp * TRACE_BLOCK] = (StackT)c; sp++; }
+                            else {
+                                wstack[sp * TRACE_BLOCK] = (StackT)c; sp++;
+                            }
                             continue;
                         }
                         // leaf: its (<= 3) triangles, each fetched once for the wave; the reference's fp64 test on the ORIGINAL ray
@@ -1062,7 +1064,11 @@ DEV double *ws_at(const Workspace &ws, int slot) {
     asm volatile("" : "+v"(lane));  // recompute the offset at every use: hoisted out of the main loop, one VGPR per slot would be spilled to scratch
     return (double *)((char *)ws.base + ((__umul24((unsigned)slot, ws.stride) + lane) << 3));
 }
+#ifdef RAYHS_PROBE_WS_TWICE  // development: every workspace store is made twice (a second copy behind the first): what do the HBM writes cost?
+DEV void ws_store(const Workspace &ws, int slot, double v) { *ws_at(ws, slot) = v; *ws_at(ws, slot + LANE_SLOTS + 3 * FRAME_SLOTS) = v; }
+#else
 DEV void ws_store(const Workspace &ws, int slot, double v) { *ws_at(ws, slot) = v; }
+#endif
 DEV double ws_load(const Workspace &ws, int slot) { return *ws_at(ws, slot); }
 DEV void ws_store3(const Workspace &ws, int slot, V3 v) { ws_store(ws, slot, v.x); ws_store(ws, slot + 1, v.y); ws_store(ws, slot + 2, v.z); }
 DEV V3 ws_load3(const Workspace &ws, int slot) { return mk(ws_load(ws, slot), ws_load(ws, slot + 1), ws_load(ws, slot + 2)); }
@@ -1131,7 +1137,16 @@ static __device__ __forceinline__ void trace_body() {
     unsigned long long chunk_t0 = 0;  // when the current chunk was obtained, and the tile it belongs to (a chunk never straddles tiles)
     int chunk_tile = 0;
     unsigned long long ticket_ahead = 0;  // lane 0: ticket of `range` requested ahead of need
-    if (lane == 0) ticket_ahead = atomicAdd(kargs()->ticket + range * TICKET_STRIDE, (unsigned long long)kChunk);
+    // The FIRST chunk of a wave is not drawn but follows from where the wave sits in the grid: band = workgroup mod 8, place in
+    // the band = (workgroup / 8) * 4 + wave.  The counters then only hand out what lies behind those places: a ticket c of band r
+    // stands for item c + pre_items(r), pre_items(r) = 256 * (workgroups b < grid with b mod 8 == r).  At the start of a launch
+    // every wave of the chip used to queue at eight counters for its first ticket (operations on one line are served ~10 ns
+    // apart: 512 waves per line) before it could generate a single ray.
+    auto pre_items = [&](int r) { return (unsigned long long)(((unsigned)gridDim.x + 7u - (unsigned)r) >> 3) * (unsigned long long)TRACE_BLOCK; };
+    const int xcc_range = range;
+    range = (int)(blockIdx.x & (kRanges - 1));
+    ticket_ahead = (unsigned long long)(((unsigned)blockIdx.x >> 3) * (TRACE_BLOCK / 64) + ((unsigned)tid >> 6)) * kChunk - pre_items(range);
+    bool first_chunk = true;
 
     // this lane's pixel (column, local row) and sample within the chunk the wave holds
     auto locate = [&](const auto &prm, int &px, int &lrow, int &sample) {
@@ -1196,6 +1211,7 @@ static __device__ __forceinline__ void trace_body() {
                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)c);
                     const unsigned long long start = (unsigned long long)range * per_range;
                     const unsigned long long size = start >= total_items ? 0ull : (total_items - start < per_range ? total_items - start : per_range);
+                    c += pre_items(range);
                     if (c < size) { chunk_item0 = start + c; break; }  // sizes are multiples of 64: the chunk is whole
                     // This range is dry.  Before walking on to the next one, note the fact in a line of eight "this range is dry"
                     // flags behind the counters and look at the other seven.  The line is kept per XCD: written and read at
@@ -1222,6 +1238,7 @@ static __device__ __forceinline__ void trace_body() {
                     if (lane == 0) c = atomicAdd(ticket + range * TICKET_STRIDE, (unsigned long long)kChunk);
                 }
                 if (exhausted) break;
+                if (first_chunk) { first_chunk = false; if (ranges_done == 0) range = xcc_range; }  // from here on: the band of the XCD this wave runs on
                 if (lane == 0) ticket_ahead = atomicAdd(ticket + range * TICKET_STRIDE, (unsigned long long)kChunk);
                 // a chunk (64 consecutive items, 64-aligned) never straddles tiles: its tile is wave-uniform and comes
                 // through the scalar cache, in the order the previous frame measured, slowest first (rayhs_order_tiles)

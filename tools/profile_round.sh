@@ -24,6 +24,10 @@ pmc sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 pmc sq2 SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_FLAT GRBM_GUI_ACTIVE || exit 6
 # instruction mix: what the vector pipe is really asked for (fp64 arithmetic runs at half rate, transcendentals at an eighth) and the branches
 pmc mix SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES || exit 7
+# round 5: what the vector pipe is asked for BESIDES fp64 (fp32 arithmetic occupies a SIMD for 2 cycles per wave64 instruction, integer /
+# compare / select / convert for 4: profiles/r05/micro/issue_rates.txt), and the scalar unit's own cycle counters
+pmc mix2 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU || echo "pmc pass mix2 failed"
+pmc sca SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU2 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH GRBM_GUI_ACTIVE || echo "pmc pass sca failed"
 # scalar data cache (the packet walk fetches its nodes and triangles through it) and instruction cache; optional passes: a
 # counter this rocprofv3 build does not know must not lose the rest of the profile
 pmc sqc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE || echo "pmc pass sqc failed"

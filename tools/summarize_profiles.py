@@ -45,8 +45,14 @@ for f in newest(f"{pre}_trace/*/*_kernel_trace.csv"):
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows[len(rows) - after - steps:len(rows) - after]]
         out["timed_launches"] = {"kernel": rows[-1]["Kernel_Name"], "launches": steps, "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d),
                                  "bench_events_avg_ms": tb.get("kernel_ms_rank0"), "first_frame_ms": tb.get("first_frame_ms")}
-# SIMD-cycles one instruction costs at full occupancy (profiles/r04/micro/issue_rates.txt, column w32)
-ISSUE_COST = {"any": 1.0, "fp64": 1.93, "fp64_trans": 6.0}
+# What one wave64 instruction costs the unit that executes it (tools/micro/issue_rates.hip -> profiles/r05/micro/issue_rates.txt: SIMD busy span /
+# instructions executed on it, residency measured, not assumed).  VALU, in cycles of its SIMD: fp32 add / mul / fma / min / max / mov 2.2 (the guide's
+# nominal 2: a SIMD is 32 lanes wide); fp64 add / mul / fma, packed fp32, every integer, compare, select and convert instruction 4.1 (nominal 4);
+# fp64 rcp / rsq / sqrt 16.  SCALAR: a CU has ONE scalar unit for its four SIMDs; it retires 0.95 instructions per cycle (4.2 SIMD-cycles per
+# instruction with all four SIMDs asking), whatever the waves per SIMD.  Vector and scalar instructions of different waves issue side by side,
+# so a launch is bounded by the busier of the two: roofline.frac = max(valu_pipe_frac, scalar_unit_frac).
+VALU_COST = {"f32_arith": 2.0, "f64_arith": 4.0, "f64_trans": 16.0, "f32_trans": 8.0, "int_cvt": 4.0, "other_nominal": 2.0, "other_measured": 4.0}
+SCALAR_COST_CU_CYCLES = 1.05   # per SALU / scalar-memory / branch instruction
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in [g for d in glob.glob(f"{pre}_pmc_*") for g in newest(f"{d}/*/*_counter_collection.csv")]:
     for r in csv.DictReader(open(f)):
@@ -84,22 +90,32 @@ for k, d in out["pmc_mean_per_launch"].items():
         d["fp64_flops_per_launch"] = 64.0 * (f64[0] + f64[1] + 2 * f64[2])   # wave-level instructions x 64 lanes (an upper bound: idle lanes count)
     if "SQ_INSTS_BRANCH" in d and "SQ_INSTS_VALU" in d:
         d["branches_per_valu"] = d["SQ_INSTS_BRANCH"] / d["SQ_INSTS_VALU"]
-    # THE ROOF THAT BINDS: instruction issue.  tools/micro/issue_rates.hip (profiles/r04/micro/issue_rates.txt) measures what a
-    # SIMD of gfx950 issues: with all 8 wave slots occupied, one instruction of ANY class per ~1.0 cycle (scalar, fp32 /
-    # integer vector, branch: 0.88-1.12 SIMD-cycles each, alone or mixed), one fp64 add / mul / fma per 1.93, one fp64
-    # rcp / rsq / sqrt per 6.0.  issue_slots = instructions priced at those costs; the SIMD-cycles of the launch are the peak.
-    # A single wave that shares its SIMD issues one instruction per ~8.3 cycles in mixed scalar / vector code whatever
-    # the number of co-resident waves (2..8): `wave_cadence_*` prices the launch against what its OWN occupancy can issue.
+    # The two roofs (see VALU_COST above).  valu_pipe_frac prices "other" vector instructions -- moves, compares, selects, lane reads: what no
+    # class counter covers -- at the guide's nominal 2 cycles (a lower bound: measured, only v_mov is that cheap); valu_pipe_frac_measured_costs
+    # at the 4 cycles compares and selects really take (an upper bound).  The fp32 / integer / convert split needs the round-5 `mix2` pass.
     classes = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")
     if all(c in d for c in classes) and all(v is not None for v in f64) and "SQ_INSTS_VALU_TRANS_F64" in d and "GRBM_GUI_ACTIVE" in d:
         insts = sum(d[c] for c in classes)     # (SQ_INSTS_FLAT counts the same global_* instructions as VMEM_RD + VMEM_WR)
         arith, trans = sum(f64), d["SQ_INSTS_VALU_TRANS_F64"]
         simd_cycles = d["GRBM_GUI_ACTIVE"] / 8 * 256 * 4
+        cu_cycles = d["GRBM_GUI_ACTIVE"] / 8 * 256
         d["insts_per_launch"] = insts
-        d["issue_slots_per_launch"] = (insts - arith - trans) * ISSUE_COST["any"] + arith * ISSUE_COST["fp64"] + trans * ISSUE_COST["fp64_trans"]
         d["simd_cycles_per_launch"] = simd_cycles
-        d["issue_frac"] = d["issue_slots_per_launch"] / simd_cycles
         d["insts_per_simd_cycle"] = insts / simd_cycles
+        f32 = [d.get("SQ_INSTS_VALU_" + k) for k in ("ADD_F32", "MUL_F32", "FMA_F32")]
+        if all(v is not None for v in f32):
+            f32a, f32t = sum(f32), d.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+            intc = d.get("SQ_INSTS_VALU_INT32", 0.0) + d.get("SQ_INSTS_VALU_INT64", 0.0) + d.get("SQ_INSTS_VALU_CVT", 0.0)
+            other = max(d["SQ_INSTS_VALU"] - arith - trans - f32a - f32t - intc, 0.0)
+            base = VALU_COST["f32_arith"] * f32a + VALU_COST["f64_arith"] * arith + VALU_COST["f64_trans"] * trans + VALU_COST["f32_trans"] * f32t + VALU_COST["int_cvt"] * intc
+            d["valu_class_counts"] = {"f32_arith": f32a, "f64_arith": arith, "f64_trans": trans, "f32_trans": f32t, "int_cvt": intc, "other": other}
+            d["valu_pipe_frac"] = (base + VALU_COST["other_nominal"] * other) / simd_cycles
+            d["valu_pipe_frac_measured_costs"] = (base + VALU_COST["other_measured"] * other) / simd_cycles
+        scalar = d["SQ_INSTS_SALU"] + d["SQ_INSTS_SMEM"] + d["SQ_INSTS_BRANCH"]
+        d["scalar_unit_insts_per_launch"] = scalar
+        d["scalar_unit_frac"] = SCALAR_COST_CU_CYCLES * scalar / cu_cycles
+        d["roofline_frac"] = max(d.get("valu_pipe_frac", 0.0), d["scalar_unit_frac"])
+        d["roofline_bound"] = "valu" if d.get("valu_pipe_frac", 0.0) >= d["scalar_unit_frac"] else "scalar-issue"
     for cache in ("DCACHE", "ICACHE"):
         if f"SQC_{cache}_REQ" in d and f"SQC_{cache}_MISSES" in d and d[f"SQC_{cache}_REQ"] > 0:
             d[f"scalar_{cache.lower()}_hit_rate"] = 1.0 - (d[f"SQC_{cache}_MISSES"] + d.get(f"SQC_{cache}_MISSES_DUPLICATE", 0.0)) / d[f"SQC_{cache}_REQ"]
@@ -119,7 +135,8 @@ if os.path.exists(pre + "_launch.txt"):
         disp["launch"] = {"variant": int(m.group(1)), "lds_bytes_per_workgroup": int(m.group(2)), "workgroups_per_cu": int(m.group(3)), "stack_cap": int(m.group(4)),
                           "workgroup_size": 256, "waves_per_simd": int(m.group(3))}
 out["dispatch"] = disp
-out["issue_cost_simd_cycles"] = ISSUE_COST
+out["valu_cost_simd_cycles"] = VALU_COST
+out["scalar_cost_cu_cycles"] = SCALAR_COST_CU_CYCLES
 for name, to in ((f"{tag}_{wl}_bench.json", "bench.json"), (f"{tag}_{wl}_trace_bench.json", "trace_bench.json")):
     p = os.path.join(src, name)
     if os.path.exists(p):
