@@ -16,15 +16,15 @@ are provably irrelevant -- zero light term -- and therefore skipped).  The frame
 scaling is "strong".
 
 Extra objects on the JSON line:
-  roofline     the roof that BINDS this kernel: instruction issue.  achieved = issue slots the
-               trace kernel consumes per second (instructions of one launch from the committed
-               rocprofv3 counter passes of this very kernel source, priced in SIMD-cycles by
-               tools/micro/issue_rates.hip: 1 per instruction, 1.93 per fp64 add/mul/fma, 6 per
-               fp64 rcp/rsq/sqrt) / the launch's mean HIP-event duration measured here; peak =
-               1024 SIMDs x 2.4 GHz.  `hbm_contract` keeps SURVEY.md 8(d)'s figures: algorithmic
-               bytes (32 B per box test, 36 B per triangle test, 40 B per plane/sphere test, 60 B
-               per shaded hit, 12 B per pixel) / the same duration against the 8 TB/s HBM peak --
-               a work rate served by the caches (the scene is 13 MB), not a bandwidth.
+  roofline     the roof that BINDS this kernel: instruction throughput.  Two units of a CU are priced with
+               costs measured on this chip (tools/micro/issue_rates.hip) and the instruction counts of this very
+               kernel source (committed rocprofv3 passes, or three short --pmc child runs of this script) over
+               the launch's mean HIP-event duration measured here: the four vector pipes (2 / 4 / 16 cycles per
+               wave64 instruction by class) and the one scalar unit all four SIMDs share (1.05 cycles per scalar
+               instruction).  `bound` names the busier one, `frac` is its occupancy.  `hbm_contract` keeps
+               SURVEY.md 8(d)'s figures: algorithmic bytes (32 B per box test, 36 B per triangle test, 40 B per
+               plane/sphere test, 60 B per shaded hit, 12 B per pixel) / the same duration against the 8 TB/s
+               HBM peak -- a work rate served by the caches (the scene is 13 MB), not a bandwidth.
   cpu_baseline the CPU oracle (a C port of the reference algorithm: exhaustive
                traversal, recursive shading) timed on this host on a bounded sample
                of the same frame.  Reported, not the target.
@@ -55,11 +55,15 @@ STRIPE_ROWS = 8
 _WORLD = int(os.environ.get("WORLD_SIZE", "1"))
 IN_FLIGHT = int(os.environ.get("RAYHS_BENCH_IN_FLIGHT", "0")) or (2 if _WORLD > 1 else 1)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-# issue roof (same guide: 256 CUs x 4 SIMDs, 2400 MHz max clock; one instruction per SIMD-cycle with all wave slots occupied,
-# profiles/r04/micro/issue_rates.txt)
-N_SIMDS, MAX_CLOCK_GHZ = 1024, 2.4
-ISSUE_PEAK_GSLOTS = N_SIMDS * MAX_CLOCK_GHZ
-WAVE_CADENCE_CYCLES = 8.3  # cycles between two instructions of ONE wave that shares its SIMD (mixed scalar / vector code, 2..8 waves per SIMD: same file)
+# The two instruction-throughput roofs of a CU (same guide: 256 CUs x 4 SIMDs, 2400 MHz max clock; unit costs measured by
+# tools/micro/issue_rates.hip, profiles/r05/micro/issue_rates.txt -- SIMD busy span / instructions executed, residency measured):
+#   vector pipe: a wave64 instruction occupies its SIMD for 2 cycles (fp32 add / mul / fma / min / max, v_mov: the guide's SIMD-32), 4 cycles
+#                (fp64 add / mul / fma, integer, convert; compares and selects when they follow one another), 16 (fp64 rcp / rsq / sqrt);
+#   scalar unit: ONE per CU, shared by its four SIMDs, 0.95 SALU / scalar-memory / branch instructions per cycle (1.05 cycles each).
+# Vector and scalar instructions of different waves issue side by side: a launch is bounded by the busier of the two.
+N_CUS, N_SIMDS, MAX_CLOCK_GHZ = 256, 1024, 2.4
+VALU_COST = {"f32_arith": 2.0, "f64_arith": 4.0, "f64_trans": 16.0, "f32_trans": 8.0, "int_cvt": 4.0, "other_nominal": 2.0, "other_measured": 4.0}
+SCALAR_COST_CU_CYCLES = 1.05
 
 
 def algorithmic_bytes(st):
@@ -106,16 +110,16 @@ def profile_counters(workload, kernel_ms):
         "salu_per_valu": c.get("salu_per_valu"),
         "valu_insts_per_launch": c.get("SQ_INSTS_VALU"),
         # round 3's instruction-mix pass: what the vector PIPE is occupied for (fp64 at half rate), what a wave does with its life
-        "valu_pipe_frac": c.get("valu_pipe_frac"),
         "valu_f64_share_of_insts": c.get("valu_f64_share_of_insts"),
         "fp64_tflops_issued": (c["fp64_flops_per_launch"] / sec / 1e12) if "fp64_flops_per_launch" in c else None,
         "fp64_peak_tflops": 78.6,
         "wave_issuing_frac": c.get("SQ_ACTIVE_INST_ANY_per_wave_cycle"),
         "wave_waitcnt_frac": c.get("SQ_WAIT_INST_ANY_per_wave_cycle"),
         "branches_per_valu": c.get("branches_per_valu"),
-        # round 4: the issue roof (tools/summarize_profiles.py) and the scalar / instruction cache hit rates
+        # round 5: the two roofs (tools/summarize_profiles.py): instruction counts by cost class
         "insts_per_launch": c.get("insts_per_launch"),
-        "issue_slots_per_launch": c.get("issue_slots_per_launch"),
+        "valu_class_counts": c.get("valu_class_counts"),
+        "scalar_unit_insts_per_launch": c.get("scalar_unit_insts_per_launch"),
         "waves_per_simd": waves,
         "scalar_dcache_hit_rate": c.get("scalar_dcache_hit_rate"),
         "scalar_icache_hit_rate": c.get("scalar_icache_hit_rate"),
@@ -124,7 +128,7 @@ def profile_counters(workload, kernel_ms):
 
 def live_instruction_counts(workload, fma):
     """Fallback when no committed profile matches this kernel source: count the trace kernel's instructions NOW, with two
-    short rocprofv3 --pmc passes of this very script as child processes (counters in their own runs, nothing else traced;
+    short rocprofv3 --pmc passes of this very script as child processes (three: instruction classes, the fp64 mix, the fp32 / integer mix) (counters in their own runs, nothing else traced;
     `--pmc-child` keeps the children from doing the same).  Each pass gets at most 75 s (a pass takes ~15 s on a warm box, most
     of it the interpreter and torch coming up).  Returns (fields the issue roof needs, None) or (None, why not)."""
     import csv, glob, shutil, subprocess, tempfile
@@ -133,7 +137,8 @@ def live_instruction_counts(workload, fma):
     if not shutil.which("rocprofv3"):
         return None, "rocprofv3 not on PATH"
     passes = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"],
-              ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"]]
+              ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"],
+              ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT"]]
     vals = {}
     tmp = tempfile.mkdtemp(prefix="rayhs_pmc_", dir="/tmp")
     try:
@@ -159,10 +164,15 @@ def live_instruction_counts(workload, fma):
         insts = sum(vals[c] for c in passes[0])
         arith = vals["SQ_INSTS_VALU_ADD_F64"] + vals["SQ_INSTS_VALU_MUL_F64"] + vals["SQ_INSTS_VALU_FMA_F64"]
         trans = vals["SQ_INSTS_VALU_TRANS_F64"]
-        return {"insts_per_launch": insts, "issue_slots_per_launch": (insts - arith - trans) + 1.93 * arith + 6.0 * trans,
+        f32a = vals["SQ_INSTS_VALU_ADD_F32"] + vals["SQ_INSTS_VALU_MUL_F32"] + vals["SQ_INSTS_VALU_FMA_F32"]
+        intc = vals["SQ_INSTS_VALU_INT32"] + vals["SQ_INSTS_VALU_INT64"] + vals["SQ_INSTS_VALU_CVT"]
+        classes = {"f32_arith": f32a, "f64_arith": arith, "f64_trans": trans, "f32_trans": vals["SQ_INSTS_VALU_TRANS_F32"], "int_cvt": intc,
+                   "other": max(vals["SQ_INSTS_VALU"] - arith - trans - f32a - vals["SQ_INSTS_VALU_TRANS_F32"] - intc, 0.0)}
+        return {"insts_per_launch": insts, "valu_class_counts": classes,
+                "scalar_unit_insts_per_launch": vals["SQ_INSTS_SALU"] + vals["SQ_INSTS_SMEM"] + vals["SQ_INSTS_BRANCH"],
                 "valu_f64_share_of_insts": (arith + trans) / vals["SQ_INSTS_VALU"], "salu_per_valu": vals["SQ_INSTS_SALU"] / vals["SQ_INSTS_VALU"],
                 "branches_per_valu": vals["SQ_INSTS_BRANCH"] / vals["SQ_INSTS_VALU"], "valu_insts_per_launch": vals["SQ_INSTS_VALU"],
-                "valu_f64_arith_per_launch": arith, "valu_f64_trans_per_launch": trans}, None
+                "fp64_flops_per_launch": 64.0 * (vals["SQ_INSTS_VALU_ADD_F64"] + vals["SQ_INSTS_VALU_MUL_F64"] + 2 * vals["SQ_INSTS_VALU_FMA_F64"])}, None
     except Exception as e:
         return None, f"{type(e).__name__}: {e}"
     finally:
@@ -412,37 +422,51 @@ def main():
         # served by L1 / scalar cache / L2 and exceeds the HBM peak: a work rate, not a bandwidth.
         src, ctr = profile_counters(args.workload, kernel_ms) if world == 1 else ({"profile": None, "matches_this_kernel": False}, None)
         if ctr is None and world == 1 and not args.pmc_child:
-            # no committed profile of THIS kernel source: count its instructions now (two short rocprofv3 --pmc child runs);
-            # the HBM / cache / wave-life figures, which need five more passes, stay null
+            # no committed profile of THIS kernel source: count its instructions now (three short rocprofv3 --pmc child runs);
+            # the HBM / cache / wave-life figures, which need more passes, stay null
             live, why_not = live_instruction_counts(args.workload, args.fma)
             if not live:
                 src = {**src, "live_pmc_passes_in_this_run": False, "live_pmc_failure": why_not}
             if live:
                 names = ("traffic", "hbm_traffic_frac", "hbm_read_frac", "hbm_write_bytes", "l2_hit_rate", "valu_busy", "valu_lane_util", "wave_wait_frac",
-                         "valu_pipe_frac", "fp64_tflops_issued", "wave_issuing_frac", "wave_waitcnt_frac", "scalar_dcache_hit_rate", "scalar_icache_hit_rate")
-                ctr = {**{k: None for k in names}, "fp64_peak_tflops": 78.6, "waves_per_simd": 4, **live}
+                         "wave_issuing_frac", "wave_waitcnt_frac", "scalar_dcache_hit_rate", "scalar_icache_hit_rate")
+                ctr = {**{k: None for k in names}, "fp64_peak_tflops": 78.6, "waves_per_simd": 4, **live,
+                       "fp64_tflops_issued": live["fp64_flops_per_launch"] / (kernel_ms * 1e-3) / 1e12}
                 src = {**src, "live_pmc_passes_in_this_run": True}
         sec = kernel_ms * 1e-3
-        slots = ctr and ctr.get("issue_slots_per_launch")
-        issue_achieved = slots / sec / 1e9 if slots else None
-        cadence = None
-        if ctr and ctr.get("insts_per_launch"):
-            per_simd_cycle = ctr["insts_per_launch"] / sec / 1e9 / ISSUE_PEAK_GSLOTS   # instructions per SIMD-cycle at the 2.4 GHz the peak assumes
-            possible = ctr["waves_per_simd"] / WAVE_CADENCE_CYCLES
-            cadence = {"cycles_between_instructions_of_a_wave": WAVE_CADENCE_CYCLES, "waves_per_simd": ctr["waves_per_simd"],
-                       "insts_per_simd_cycle_possible": possible, "insts_per_simd_cycle_achieved": per_simd_cycle, "frac": per_simd_cycle / possible}
-        roofline = {"bound": "issue", "achieved": issue_achieved, "peak": ISSUE_PEAK_GSLOTS, "unit": "G issue-slots/s (SIMD-cycles of issue per second)",
-                    "frac": issue_achieved / ISSUE_PEAK_GSLOTS if issue_achieved else None,
+        cls = ctr and ctr.get("valu_class_counts")
+        valu = scalar = None
+        if cls:
+            base = sum(VALU_COST[k] * cls[k] for k in ("f32_arith", "f64_arith", "f64_trans", "f32_trans", "int_cvt"))
+            peak = N_SIMDS * MAX_CLOCK_GHZ
+            valu = {"unit": "G SIMD-cycles/s", "peak": peak,
+                    "achieved": (base + VALU_COST["other_nominal"] * cls["other"]) / sec / 1e9,
+                    "achieved_measured_costs": (base + VALU_COST["other_measured"] * cls["other"]) / sec / 1e9}
+            valu["frac"] = valu["achieved"] / peak
+            valu["frac_measured_costs"] = valu["achieved_measured_costs"] / peak
+        if ctr and ctr.get("scalar_unit_insts_per_launch"):
+            peak = N_CUS * MAX_CLOCK_GHZ
+            scalar = {"unit": "G CU-cycles/s", "peak": peak, "achieved": SCALAR_COST_CU_CYCLES * ctr["scalar_unit_insts_per_launch"] / sec / 1e9}
+            scalar["frac"] = scalar["achieved"] / peak
+        binding = None
+        if valu and scalar:
+            binding = ("valu", valu) if valu["frac"] >= scalar["frac"] else ("scalar-issue", scalar)
+        roofline = {"bound": binding[0] if binding else "scalar-issue", "achieved": binding[1]["achieved"] if binding else None,
+                    "peak": binding[1]["peak"] if binding else N_CUS * MAX_CLOCK_GHZ, "unit": binding[1]["unit"] if binding else "G CU-cycles/s",
+                    "frac": binding[1]["frac"] if binding else None,
                     "traffic": ctr["traffic"] if ctr else None,
-                    "model": "issue slots = instructions of one launch (rocprofv3 SQ_INSTS_* of this kernel source, profiles/) at 1 SIMD-cycle each, fp64 add/mul/fma 1.93, "
-                             "fp64 rcp/rsq/sqrt 6.0 (tools/micro/issue_rates.hip, profiles/r04/micro/issue_rates.txt) / this run's mean HIP-event duration; "
-                             "peak = 1024 SIMDs x 2.4 GHz, one instruction per SIMD-cycle with all 8 wave slots occupied",
-                    "insts_per_launch": ctr and ctr.get("insts_per_launch"), "issue_slots_per_launch": slots,
-                    "occupancy_limited_issue": cadence,
-                    "bound_actual": "instruction issue at the occupancy the fp64 state allows: the kernel holds 128 VGPRs = 4 waves/SIMD, a wave that shares its SIMD "
-                                    "issues one instruction per ~8.3 cycles, so 4 waves can issue 0.48 instructions per SIMD-cycle and the kernel issues "
-                                    "occupancy_limited_issue.frac of that (the rest: waits on scalar-cache / LDS / L2 round trips); HBM (3 % of peak, the "
-                                    "scene stays in cache) and the vector pipe (valu_pipe_frac) are far from full (DESIGN.md section 4)",
+                    "model": "the larger of two instruction-throughput roofs, both priced with unit costs measured on this chip (tools/micro/issue_rates.hip, "
+                             "profiles/r05/micro/issue_rates.txt) and instruction counts of this kernel source (rocprofv3 SQ_INSTS_* passes) over this run's mean "
+                             "HIP-event duration at 2.4 GHz: 'valu' = cycles the four vector pipes of a CU are occupied (2 per fp32 add/mul/fma and per instruction no "
+                             "class counter covers, 4 per fp64 add/mul/fma / integer / convert, 16 per fp64 rcp/rsq/sqrt); 'scalar-issue' = the ONE scalar unit of a CU, "
+                             "1.05 cycles per SALU / scalar-memory / branch instruction of any of its 16 waves",
+                    "valu_pipe": valu, "scalar_unit": scalar,
+                    "valu_class_counts": cls, "scalar_unit_insts_per_launch": ctr and ctr.get("scalar_unit_insts_per_launch"),
+                    "insts_per_launch": ctr and ctr.get("insts_per_launch"),
+                    "bound_actual": "instruction throughput: the scalar unit of a CU (shared by its 16 resident waves) and the vector pipes are both about two thirds "
+                                    "busy (valu_pipe.frac_measured_costs prices compares, selects and lane reads at the 4 cycles they take back to back, an upper "
+                                    "bound); with 4 waves per SIMD (128 VGPRs of fp64 state) the rest is waits on scalar-cache / LDS / L2 round trips; HBM (3 % of "
+                                    "peak, the scene stays in cache) is nowhere near (DESIGN.md section 4)",
                     "scalar_dcache_hit_rate": ctr and ctr.get("scalar_dcache_hit_rate"), "scalar_icache_hit_rate": ctr and ctr.get("scalar_icache_hit_rate"),
                     # SURVEY.md 8(d)'s contract figures: algorithmic bytes / kernel time against the HBM peak (> 1: the bytes are served by the caches)
                     "hbm_contract": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -452,8 +476,8 @@ def main():
                     "valu_busy": ctr and ctr["valu_busy"], "valu_lane_util": ctr and ctr["valu_lane_util"],
                     "wave_wait_frac": ctr and ctr["wave_wait_frac"], "salu_per_valu": ctr and ctr["salu_per_valu"],
                     "valu_insts_per_launch": ctr and ctr["valu_insts_per_launch"],
-                    **({k: ctr[k] for k in ("valu_pipe_frac", "valu_f64_share_of_insts", "fp64_tflops_issued", "fp64_peak_tflops", "wave_issuing_frac",
-                                            "wave_waitcnt_frac", "branches_per_valu")} if ctr else {}),
+                    **({k: ctr.get(k) for k in ("valu_f64_share_of_insts", "fp64_tflops_issued", "fp64_peak_tflops", "wave_issuing_frac",
+                                                "wave_waitcnt_frac", "branches_per_valu")} if ctr else {}),
                     "counters_from": src}
         out = {
             "metric": "Mrays/s", "value": rays_frame * args.steps / dt / 1e6, "unit": "Mrays/s",

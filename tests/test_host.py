@@ -397,10 +397,11 @@ def test_cli_argument_errors_mirror_the_reference():
     assert r.returncode == 1 and r.stdout.startswith("Loading scene from data/nope.json...")
 
 
-def test_committed_profiles_carry_the_issue_roofline_bench_py_prices_with():
-    # bench.py's `roofline` (the binding roof: instruction issue) takes the trace kernel's instruction counts from
-    # profiles/rNN/<workload>/summary.json when that profile was taken on this very kernel source.  The derived fields must
-    # be there and consistent with the raw counters (tools/summarize_profiles.py), and the fraction must be a fraction.
+def test_committed_profiles_carry_the_two_roofs_bench_py_prices_with():
+    # bench.py's `roofline` (the larger of the vector-pipe and the scalar-unit occupancy) takes the trace kernel's instruction
+    # counts, by cost class, from profiles/rNN/<workload>/summary.json when that profile was taken on this very kernel source.
+    # The derived fields must be there and consistent with the raw counters (tools/summarize_profiles.py), and every fraction
+    # must be a fraction -- also when re-priced at bench.py's peak with the profile's own kernel time.
     import glob
     import bench
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "dragon", "summary.json")))
@@ -408,16 +409,19 @@ def test_committed_profiles_carry_the_issue_roofline_bench_py_prices_with():
     d = json.load(open(files[-1]))
     c = next(v for k, v in d["pmc_mean_per_launch"].items() if "count" not in k)
     classes = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")
-    insts = sum(c[k] for k in classes)
-    arith = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"]
-    trans = c["SQ_INSTS_VALU_TRANS_F64"]
-    cost = d["issue_cost_simd_cycles"]
-    assert c["insts_per_launch"] == pytest.approx(insts)
-    assert c["issue_slots_per_launch"] == pytest.approx((insts - arith - trans) * cost["any"] + arith * cost["fp64"] + trans * cost["fp64_trans"])
-    assert 0 < c["issue_frac"] <= 1 and 0 < c["scalar_dcache_hit_rate"] <= 1
-    # priced at bench.py's peak (1024 SIMDs x 2.4 GHz) with the profile's own kernel time the fraction stays a fraction
-    frac = c["issue_slots_per_launch"] / (d["timed_launches"]["avg_ms"] * 1e-3) / 1e9 / bench.ISSUE_PEAK_GSLOTS
-    assert 0 < frac <= 1
+    assert c["insts_per_launch"] == pytest.approx(sum(c[k] for k in classes))
+    cls, cost = c["valu_class_counts"], d["valu_cost_simd_cycles"]
+    assert cost == bench.VALU_COST and d["scalar_cost_cu_cycles"] == bench.SCALAR_COST_CU_CYCLES
+    assert sum(cls.values()) == pytest.approx(c["SQ_INSTS_VALU"])
+    assert cls["f64_arith"] == pytest.approx(c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"])
+    assert c["scalar_unit_insts_per_launch"] == pytest.approx(c["SQ_INSTS_SALU"] + c["SQ_INSTS_SMEM"] + c["SQ_INSTS_BRANCH"])
+    assert 0 < c["valu_pipe_frac"] <= c["valu_pipe_frac_measured_costs"] <= 1 and 0 < c["scalar_unit_frac"] <= 1
+    assert c["roofline_frac"] == max(c["valu_pipe_frac"], c["scalar_unit_frac"]) and c["roofline_bound"] in ("valu", "scalar-issue")
+    assert 0 < c["scalar_dcache_hit_rate"] <= 1
+    sec = d["timed_launches"]["avg_ms"] * 1e-3
+    base = sum(cost[k] * cls[k] for k in ("f32_arith", "f64_arith", "f64_trans", "f32_trans", "int_cvt"))
+    assert 0 < (base + cost["other_measured"] * cls["other"]) / sec / 1e9 / (bench.N_SIMDS * bench.MAX_CLOCK_GHZ) <= 1
+    assert 0 < bench.SCALAR_COST_CU_CYCLES * c["scalar_unit_insts_per_launch"] / sec / 1e9 / (bench.N_CUS * bench.MAX_CLOCK_GHZ) <= 1
     if d.get("kernel_source_sha256") != bench.kernel_source_sha256():
         pytest.skip("the committed profile was taken on another kernel source: bench.py will count instructions live (rocprofv3 --pmc child runs); "
                     "re-run tools/profile_round.sh + tools/summarize_profiles.py before the round ends")

@@ -6,7 +6,7 @@ are ignored: the .loc line is where the instruction's expression was written) an
 the sections of the kernel -- a static mix, to be weighed with the trip counts of a -DRAYHS_PROFILE_LOOPS run."""
 import collections, os, re, subprocess, sys
 SRC = "/root/repo/rayhs_amd/csrc/trace_kernel.hip"
-asm = sys.argv[1] if len(sys.argv) > 1 else None
+asm = next((a for a in sys.argv[1:] if a.endswith(".s")), None)
 if asm is None:
     os.makedirs("/tmp/kl", exist_ok=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DRAYHS_KERNEL_SUFFIX=exact",
@@ -32,6 +32,7 @@ out = subprocess.run([LLVM + "llvm-symbolizer", "--obj=" + OBJ, "--inlines", "--
 chains = [c.strip().split("\n") for c in out.strip().split("\n\n")]
 assert len(chains) == len(insts), (len(chains), len(insts))
 cnt = collections.defaultdict(lambda: [0, 0, 0])
+vclass = collections.defaultdict(collections.Counter)
 listing = []   # (address, line, opcode) for --dump
 for (addr, op), ch in zip(insts, chains):
     frames = [(ch[i], ch[i + 1]) for i in range(0, len(ch) - 1, 2)]   # innermost first: (function, file:line:col)
@@ -47,6 +48,11 @@ for (addr, op), ch in zip(insts, chains):
     listing.append((addr, line, op))
     if k is None: continue
     cnt[line][k] += 1
+    if k == 0:   # what the vector pipe is asked for, by cost class (profiles/r05/micro/issue_rates.txt): fp32 arithmetic and v_mov_b32 2 cycles, the rest 4, fp64 rcp / rsq / sqrt 16
+        c = ("trans64" if re.match(r"v_(rcp|rsq|sqrt)_f64", op) else "cmp" if op.startswith("v_cmp") else "f64" if re.search(r"_f64", op) and not op.startswith("v_cvt") else
+             "cvt" if op.startswith("v_cvt") else "f32" if re.search(r"_f32", op) else "cndmask" if op.startswith("v_cndmask") else
+             "mov" if op.startswith(("v_mov_b32", "v_accvgpr")) else "lane" if op.startswith(("v_readlane", "v_writelane", "v_readfirstlane")) else "int")
+        vclass[line][c] += 1
 src = open(SRC).read().split("\n")
 def find(pat, start=0):
     for i in range(start, len(src)):
@@ -82,6 +88,16 @@ for (name, a), (_, b) in zip(marks, marks[1:]):
 o = cnt.get(-1, [0, 0, 0])
 print(f"{'(other files: hip headers, libm)':52s} {o[0]:6d} {o[1]:6d} {o[2]:5d}")
 print(f"{'total':52s} {tot[0] + o[0]:6d} {tot[1] + o[1]:6d} {tot[2] + o[2]:5d}")
+
+if "--classes" in sys.argv:   # static VALU instructions per section by cost class
+    names = ("f64", "trans64", "f32", "mov", "cmp", "cndmask", "cvt", "lane", "int")
+    print("\n" + f"{'section (static VALU by class)':52s} " + " ".join(f"{n:>7s}" for n in names) + "   pipe-cycles")
+    cost = {"f64": 4, "trans64": 16, "f32": 2, "mov": 2, "cmp": 4, "cndmask": 4, "cvt": 4, "lane": 4, "int": 4}
+    for (name, a), (_, b) in zip(marks, marks[1:]):
+        c = collections.Counter()
+        for l in vclass:
+            if a <= l < b: c.update(vclass[l])
+        if sum(c.values()): print(f"{name:52s} " + " ".join(f"{c[n]:7d}" for n in names) + f"   {sum(cost[n] * c[n] for n in names):7d}")
 
 if "--dump" in sys.argv:   # tools/isa_lines.py asm --dump "<section name prefix>": the section's instructions in address order, with their line
     want = sys.argv[sys.argv.index("--dump") + 1]
