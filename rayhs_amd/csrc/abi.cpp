@@ -720,6 +720,9 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
 #endif
     if (term_in_lds) dp.ctx_slots = CTX_SLOTS + 3;
     lds = (size_t)dp.ctx_slots * TRACE_BLOCK * sizeof(double) + stack_bytes;
+#ifdef RAYHS_PROFILE_LOOPS
+    lds += 16;  // one word per wave of a workgroup: the per-lane-walk census of the diagnostic build (trace_kernel.hip, traverse())
+#endif
     if (lds > 160 * 1024) return set_error(RAYHS_ERR_UNSUPPORTED, "tree depth %d needs %zu B of LDS per workgroup (limit 160 KiB)", dp.stack_cap - 2, lds);
     // persistent grid: as many workgroups as the chip keeps resident
     int *cache = s->grid_cache[exact ? 1 : 0][variant];
@@ -1037,6 +1040,10 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
                              c[32], c[33], c[34], c[35], c[36], c[37], c[38], c[39]);
             if (g_cfg.debug_counters)
                 std::fprintf(stderr, "rayhs packet[40..43]: packet visits (lanes, waves) %llu %llu | %llu %llu\n", c[40], c[41], c[42], c[43]);
+            if (g_cfg.debug_counters)  // per-lane-walk census of a -DRAYHS_PROFILE_LOOPS build (trace_kernel.hip, traverse())
+                std::fprintf(stderr, "rayhs perlane[44..57]: walks by entering lanes <=4 / <=16 / <=32 / <=64: %llu %llu %llu %llu | node-loop iterations: %llu %llu %llu %llu | "
+                                     "sibling waves of the workgroup inside a per-lane walk when one starts, 0 / 1 / 2 / 3: %llu %llu %llu %llu | lanes walking in those siblings %llu, "
+                                     "entering lanes of the starting walks %llu\n", c[44], c[45], c[46], c[47], c[48], c[49], c[50], c[51], c[52], c[53], c[54], c[55], c[56], c[57]);
         }
     }
     return RAYHS_OK;

@@ -176,7 +176,8 @@ enum { CNT_PRIMARY = 0, CNT_REFLECT, CNT_REFRACT, CNT_REFRACT_EXIT, CNT_SHADOW, 
        CNT_SHADOW_SKIPPED,  // shadow queries counted in CNT_SHADOW but not traced (zero light term); slot 10 doubles as a
                             // development counter in -DRAYHS_PROFILE_LOOPS / -DRAYHS_PROFILE_TIME builds
        CNT_SLOTS = 16,
-       CNT_SLOTS_DEV = 48 };  // development builds (-DRAYHS_PROFILE_LOOPS) also write slots 16..31: the library's own buffer holds 32
+       CNT_SLOTS_DEV = 64 };  // development builds (-DRAYHS_PROFILE_LOOPS) also write slots 16..63 (trace_kernel.hip, LOOP_TICK and the
+                              // per-lane-walk census): the library's own buffer holds that many
 
 static constexpr int ORDER_MAX_BLOCKS = 64;  // workgroups of the tile-ordering kernels (one 1024-entry histogram row each)
 static constexpr int TRACE_BLOCK = 256;     // threads per workgroup (4 waves)

@@ -354,6 +354,9 @@ struct Tracer {
     typedef StackT __attribute__((address_space(3))) *stack_ptr;
     stack_ptr stack;  // this lane's LDS column: stack[level * TRACE_BLOCK]
     Counters &cnt;
+#ifdef RAYHS_PROFILE_LOOPS
+    volatile unsigned __attribute__((address_space(3))) *census_words = nullptr;  // one word per wave of the workgroup (per-lane-walk census, traverse())
+#endif
 
     // closest-hit record
     // (the barycentrics of a winning triangle are not kept: the shading section re-runs the test on that one triangle,
@@ -983,6 +986,29 @@ struct Tracer {
 #endif
             if (enter) w.t_cur = me.froot;
             TIME_ADD(12);
+#ifdef RAYHS_PROFILE_LOOPS
+            // Census of the per-lane walk (counting kernel of the -DRAYHS_PROFILE_LOOPS build; rows 44..59 of the counters): walks and their
+            // node-loop iterations by the number of lanes that enter (<= 4, <= 16, <= 32, <= 64: rows 44..47 and 48..51), and -- what a
+            // re-binning of rays between the four waves of a workgroup could draw on -- how many SIBLING waves are inside a per-lane walk of
+            // their own at the moment this one starts (0..3: rows 52..55) and the lanes still walking in those siblings at that moment
+            // (row 56), against this walk's own entering lanes (row 57).  Sixteen bytes of LDS behind the stack area hold one word per wave:
+            // the lanes it has in a per-lane walk right now (0: not walking); lane 0 of a wave is the only writer of its word.
+            int census_bucket = 0;
+            if (COUNT) {
+                const int n_enter = __popcll(em), my_wave = (int)(threadIdx.x >> 6);
+                census_bucket = n_enter <= 4 ? 0 : n_enter <= 16 ? 1 : n_enter <= 32 ? 2 : 3;
+                if ((int)__lane_id() == 0) {
+                    int siblings = 0; unsigned their_lanes = 0;
+                    for (int k = 0; k < TRACE_BLOCK / 64; k++)
+                        if (k != my_wave) { const unsigned v = census_words[k]; siblings += v != 0u; their_lanes += v; }
+                    cnt.c[44 + census_bucket]++;
+                    cnt.c[52 + siblings]++;
+                    cnt.c[56] += their_lanes;
+                    cnt.c[57] += (unsigned)n_enter;
+                    census_words[my_wave] = (unsigned)n_enter;
+                }
+            }
+#endif
             while (true) {
                 // phase 1: walk inner nodes until this lane holds a leaf (or runs out of nodes).  The body is
                 // branch-free apart from the stack push/pop: the whole 64-byte node is requested at once (one
@@ -991,11 +1017,14 @@ struct Tracer {
                 if (COUNT) {  // per pass of the while-while loop: lanes still in this traversal (32), of which holding a leaf (34)
                     if (w.traversing()) { LOOP_TICK(32); }
                     if (w.t_pa != FNODE_NONE) { LOOP_TICK(34); }
+                    const unsigned walking = (unsigned)__popcll(__ballot(w.traversing()));
+                    if ((int)__lane_id() == 0) census_words[threadIdx.x >> 6] = walking;   // (what a sibling that starts a walk now would find here)
                 }
 #endif
                 while (w.t_cur != FNODE_NONE && w.t_pa == FNODE_NONE) {
                     LOOP_TICK(10);
 #ifdef RAYHS_PROFILE_LOOPS
+                    if (COUNT && (int)__lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1) cnt.c[48 + census_bucket]++;   // node-loop iterations of walks of this size
                     if (COUNT) cnt.c[36] += (unsigned)__popcll(__ballot(true)) < 16u;   // lane-visits made in passes with < 16 lanes active
                     if (COUNT) cnt.c[37] += (unsigned)__popcll(__ballot(true)) < 32u;   // ... < 32
 #endif
@@ -1045,6 +1074,9 @@ struct Tracer {
                 TIME_ADD(14);
                 if (__ballot(w.traversing()) == 0ull) break;
             }
+#ifdef RAYHS_PROFILE_LOOPS
+            if (COUNT && (int)__lane_id() == 0) census_words[threadIdx.x >> 6] = 0u;
+#endif
         }
     }
 };
@@ -1101,6 +1133,12 @@ static __device__ __forceinline__ void trace_body() {
     stack_ptr stk = (stack_ptr)((lds_dptr)lds + ctx_slots * TRACE_BLOCK) + tid;          // stack column
     const bool term_in_lds = ctx_slots >= 15;  // wave-uniform: the launcher grants 3 more slots when LDS has room
     Tracer<EXH, COUNT, StackT> tr(stk, cnt);
+#ifdef RAYHS_PROFILE_LOOPS
+    // (the launcher of a -DRAYHS_PROFILE_LOOPS build adds 16 bytes behind the stack area)
+    tr.census_words = (volatile unsigned __attribute__((address_space(3))) *)((stack_ptr)((lds_dptr)lds + ctx_slots * TRACE_BLOCK) + PRM.stack_cap * TRACE_BLOCK);
+    if (tid < TRACE_BLOCK / 64) tr.census_words[tid] = 0u;
+    __syncthreads();
+#endif
     const Workspace ws = {kargs()->frames, (unsigned)PRM.frame_stride, (unsigned)gtid};
 
     // per-lane state that stays in registers across a scene query.  Which pixel and sample a lane works on is NOT

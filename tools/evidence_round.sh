@@ -16,7 +16,7 @@ if [ -f build_exp/binpt/librayhs_hip.so ]; then
   done
 fi
 if [ -f build_exp/binpl/librayhs_hip.so ]; then
-  RAYHS_LIB=$PWD/build_exp/binpl/librayhs_hip.so RAYHS_DEBUG_COUNTERS=1 python3 tools/kbench.py dragon 2 2>&1 | grep -E "^rayhs (adv|sections|traversal|packet)" | tail -4 > $out/${tag}_loop_counters_dragon.txt
+  RAYHS_LIB=$PWD/build_exp/binpl/librayhs_hip.so RAYHS_DEBUG_COUNTERS=1 python3 tools/kbench.py dragon 2 2>&1 | grep -E "^rayhs (adv|sections|traversal|packet|perlane)" | tail -5 > $out/${tag}_loop_counters_dragon.txt
 fi
 : > $out/${tag}_cli_timing.txt
 for args in "--spp=16 scenes/dragon_1080p.json" "--spp=4 scenes/dragon_low_1080p.json" "--spp=1 scenes/cornell_1080p_d0.json" "--spp=16 --devices=0,0 scenes/dragon_1080p.json"; do
