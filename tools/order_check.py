@@ -1,5 +1,6 @@
 """Diagnostic: is the work order a frame was given really slowest-first by the chunk times THAT frame measured?
-    python tools/order_check.py [workload]   (production kernels; uses RAYHS_DUMP_TILE_COSTS / RAYHS_DUMP_TILE_ORDER)"""
+    RAYHS_LIB=build_exp/cur/librayhs_hip.so python tools/order_check.py [workload]
+(production kernels of a -DRAYHS_DEV_KNOBS build: the chunk times come from its RAYHS_DUMP_TILE_COSTS, the order from rayhs_scene_tile_order)"""
 import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,17 +8,22 @@ from rayhs_amd import build_rendering, lib as L
 W = {"dragon": ("scenes/dragon_1080p.json", 16), "dragon_low": ("scenes/dragon_low_1080p.json", 4), "cornell": ("scenes/cornell_1080p_d0.json", 1)}
 scene, spp = W[sys.argv[1] if len(sys.argv) > 1 else "dragon"]
 r = build_rendering(scene)
-pc, po = "/tmp/tile_costs.bin", "/tmp/tile_order.bin"
-for f in (pc, po):
-    if os.path.exists(f): os.remove(f)
+pc = "/tmp/tile_costs.bin"
+if os.path.exists(pc): os.remove(pc)
+r.capture_tile_order(True)
 for i in range(5):
-    if i == 4: os.environ["RAYHS_DUMP_TILE_COSTS"] = pc; os.environ["RAYHS_DUMP_TILE_ORDER"] = po
+    if i == 4:
+        os.environ["RAYHS_DUMP_TILE_COSTS"] = pc
+        L.load().rayhs_config_reload()
     _, st = r.ray_trace(spp=spp, out_format=L.OUT_F32)
+order_given, _ = r.tile_order()
 raw = np.fromfile(pc, dtype=np.float32)
 hdr = raw[:4].view(np.int32); n = int(hdr[0])
 cost = raw[4:4 + n]            # 100 MHz ticks: longest chunk of the tile in THIS frame
-order = np.fromfile(po, dtype=np.int32)[4:4 + n]
-tile = order & ((1 << 28) - 1); prio = (order >> 28) & 3
+tile = order_given.astype(np.int64)
+# (the issue-priority class of a tile -- quarters of the slowest tile's time -- is not part of what rayhs_scene_tile_order returns: recomputed)
+top = cost[tile].max() if n else 1.0
+prio = np.where(cost[tile] > 0.75 * top, 3, np.where(cost[tile] > 0.5 * top, 2, np.where(cost[tile] > 0.25 * top, 1, 0)))
 print(f"{n} tiles, kernel {st['kernel_ms']:.3f} ms; cost (us) min {cost.min()/100:.0f} median {np.median(cost)/100:.0f} p90 {np.percentile(cost,90)/100:.0f} max {cost.max()/100:.0f}")
 per_band = -(-n // 8)
 # the trace kernel's bands: n_tiles*64*spp items cut into 8 ranges of whole chunks
