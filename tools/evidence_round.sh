@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 mkdir -p $out
 python3 tools/first_frame.py > $out/${tag}_first_frame.jsonl 2> $out/${tag}_first_frame.err
 python3 tools/stripe_balance.py dragon dragon_low dragon4k > $out/${tag}_stripe_balance.jsonl 2> $out/${tag}_stripe_balance.err
-python3 tools/tile_costs.py > $out/${tag}_static_costs.md 2> $out/${tag}_static_costs.err
+RAYHS_LIB=$PWD/build_exp/cur/librayhs_hip.so python3 tools/tile_costs.py > $out/${tag}_static_costs.md 2> $out/${tag}_static_costs.err   # (the chunk-time dump exists only in -DRAYHS_DEV_KNOBS builds)
 if [ -f build_exp/binpt/librayhs_hip.so ]; then
   for wl in dragon dragon4k; do
     RAYHS_LIB=$PWD/build_exp/binpt/librayhs_hip.so RAYHS_DEBUG_COUNTERS=1 python3 tools/kbench.py $wl 3 2>&1 | python3 tools/phase_times.py > $out/${tag}_phase_times_$wl.txt

@@ -1,6 +1,6 @@
 """Measured chunk time per 8x8 tile against the static first-frame estimate (GPU box; development aid).
 
-    python tools/tile_costs.py [raw] > gpurun_out/static_costs.md
+    RAYHS_LIB=build_exp/cur/librayhs_hip.so python tools/tile_costs.py [raw] > gpurun_out/static_costs.md      (a -DRAYHS_DEV_KNOBS build)
 Renders three frames per workload with RAYHS_DUMP_TILE_COSTS (the third frame's measured chunk times and the
 estimate of rayhs_static_costs are appended to a file by the library) and tabulates one against the other.
 `raw`: tabulate the estimate's raw feature instead (boxes of the upper BVH levels met by the tile's five rays)."""
@@ -23,8 +23,10 @@ for name, scene, spp in (("dragon", "scenes/dragon_1080p.json", 16), ("dragon_lo
     for i in range(3):
         if i == 2:
             os.environ["RAYHS_DUMP_TILE_COSTS"] = path
+            L.load().rayhs_config_reload()   # (the library reads its environment once)
         r.ray_trace(spp=spp, out_format=L.OUT_F32)
     os.environ.pop("RAYHS_DUMP_TILE_COSTS")
+    L.load().rayhs_config_reload()
     r.close()
     buf = open(path, "rb").read()
     n = int(np.frombuffer(buf[:4], dtype=np.int32)[0])

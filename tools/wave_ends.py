@@ -9,7 +9,9 @@ scene, spp = W[sys.argv[1] if len(sys.argv) > 1 else "dragon"]
 r = build_rendering(scene)
 path = "/tmp/wave_ends.bin"
 for i in range(4):
-    if i == 3: os.environ["RAYHS_DUMP_WAVE_ENDS"] = path
+    if i == 3:
+        os.environ["RAYHS_DUMP_WAVE_ENDS"] = path
+        L.load().rayhs_config_reload()   # (the library reads its environment once)
     _, st = r.ray_trace(spp=spp, flags=0 if os.environ.get("RAYHS_WAVE_ENDS_PRODUCTION") else L.FLAG_COUNT, out_format=L.OUT_F32)
 w = np.fromfile(path, dtype=np.uint64).reshape(-1, 4).astype(np.int64)
 w = w[(w[:, 3] > 0) & (w[:, 3] < 10**7) & (w[:, 1] > w[:, 0]) & (w[:, 1] - w[:, 0] < 10**9)]  # (the dump is sized for the largest grid: keep the rows waves wrote)
