@@ -772,6 +772,27 @@ def test_first_frame_static_order_is_a_permutation_that_leads_with_the_slow_tile
     assert overlap > 0.5, overlap
 
 
+def test_environment_switches_are_read_once_until_the_host_asks_again(monkeypatch):
+    # nothing on the launch path reads the environment (include/rayhs.h, rayhs_config_reload): a switch set after the library was loaded
+    # is not seen until the host asks for the environment to be read again
+    r = build_rendering("scenes/dragon_low_1080p.json")
+    r.capture_tile_order(True)
+    try:
+        img0, _ = r.ray_trace(spp=1, out_format=L.OUT_F32)
+        assert len(r.tile_order()[0]) == 240 * 135                 # ordered (static estimate: first frame of the handle)
+        monkeypatch.setenv("RAYHS_SCAN_ORDER", "1")
+        img1, _ = r.ray_trace(spp=1, out_format=L.OUT_F32)
+        assert len(r.tile_order()[0]) == 240 * 135                 # still ordered: the switch has not been read
+        L.load().rayhs_config_reload()
+        img2, _ = r.ray_trace(spp=1, out_format=L.OUT_F32)
+        assert len(r.tile_order()[0]) == 0                         # scan order now
+        assert np.array_equal(img0, img1) and np.array_equal(img0, img2)
+    finally:
+        monkeypatch.delenv("RAYHS_SCAN_ORDER", raising=False)
+        L.load().rayhs_config_reload()
+        r.close()
+
+
 def test_unknown_flag_bits_are_refused():
     r = build_rendering("scenes/cornell_96.json")
     with pytest.raises(L.RayhsError) as e:
