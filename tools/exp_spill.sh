@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 5: the RAYHS_* knobs this recipe sets exist only in -DRAYHS_DEV_KNOBS builds: build its libraries with tools/build_exp.sh <name> [flags], and use build_exp/cur -- tools/build_exp.sh cur -- where it says "default lib")
 # experiment (GPU box): what a register-limited build costs at the SAME occupancy (4 workgroups per CU)
 # usage: tools/exp_spill.sh <tag> <lib dir under build_exp> ...
 export TMPDIR=/tmp

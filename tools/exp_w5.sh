@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 5: the RAYHS_* knobs this recipe sets exist only in -DRAYHS_DEV_KNOBS builds: build its libraries with tools/build_exp.sh <name> [flags], and use build_exp/cur -- tools/build_exp.sh cur -- where it says "default lib")
 # experiment (GPU box): five workgroups per CU against four, same BVH (depth-limited so that its stack fits 32 KiB of LDS)
 # usage: tools/exp_w5.sh <tag> <lib dir under build_exp> ...
 set -o pipefail

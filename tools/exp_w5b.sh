@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 5: the RAYHS_* knobs this recipe sets exist only in -DRAYHS_DEV_KNOBS builds: build its libraries with tools/build_exp.sh <name> [flags], and use build_exp/cur -- tools/build_exp.sh cur -- where it says "default lib")
 # experiment (GPU box): a 96-VGPR build at 5 workgroups per CU against the shipped one; what each ingredient costs
 # usage: tools/exp_w5b.sh <tag> <shipped lib dir> <96-VGPR lib dir>
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 5: the RAYHS_* knobs this recipe sets exist only in -DRAYHS_DEV_KNOBS builds: build its libraries with tools/build_exp.sh <name> [flags], and use build_exp/cur -- tools/build_exp.sh cur -- where it says "default lib")
 # experiment (GPU box): is a fifth workgroup per CU resident, and what does it buy?  (-DRAYHS_PROFILE_TIME builds: counters[6] = waves that obtained work)
 export TMPDIR=/tmp
 tag=$1
