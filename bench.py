@@ -70,12 +70,34 @@ def algorithmic_bytes(st):
     return (32 * st["nodes_tested"] + 36 * st["tris_tested"] + 40 * st["prims_tested"] + 60 * st["shaded_hits"] + 12 * st["pixels"])
 
 
+def _code_only(text):
+    """C++ source without comments, blank lines and trailing blanks (string literals respected): what the compiler sees."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":                       # a literal: copied whole
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1]); i = j + 1
+        elif text.startswith("//", i):
+            while i < n and text[i] != "\n":
+                i += 1
+        elif text.startswith("/*", i):
+            i = text.find("*/", i + 2)
+            i = n if i < 0 else i + 2
+        else:
+            out.append(c); i += 1
+    return "\n".join(ln.rstrip() for ln in "".join(out).split("\n") if ln.strip()) + "\n"
+
+
 def kernel_source_sha256():
-    """Identity of the kernel being benchmarked: what tools/profile_round.sh records next to its counters."""
+    """Identity of the kernel being benchmarked: what tools/profile_round.sh records next to its counters.  Taken over the CODE of the
+    three files (comments and blank lines stripped): correcting a comment must not orphan the committed profiles."""
     import hashlib
     lines = []
     for f in ("rayhs_amd/csrc/trace_kernel.hip", "rayhs_amd/csrc/device_scene.h", "rayhs_amd/csrc/abi.cpp"):
-        lines.append(f"{hashlib.sha256(open(os.path.join(ROOT, f), 'rb').read()).hexdigest()}  {f}\n")
+        lines.append(f"{hashlib.sha256(_code_only(open(os.path.join(ROOT, f)).read()).encode()).hexdigest()}  {f}\n")
     return hashlib.sha256("".join(lines).encode()).hexdigest()
 
 
@@ -130,7 +152,7 @@ def live_instruction_counts(workload, fma):
     """Fallback when no committed profile matches this kernel source: count the trace kernel's instructions NOW, with two
     short rocprofv3 --pmc passes of this very script as child processes (three: instruction classes, the fp64 mix, the fp32 / integer mix) (counters in their own runs, nothing else traced;
     `--pmc-child` keeps the children from doing the same).  Each pass gets at most 75 s (a pass takes ~15 s on a warm box, most
-    of it the interpreter and torch coming up).  Returns (fields the issue roof needs, None) or (None, why not)."""
+    of it the interpreter and torch coming up).  Returns (fields the two roofs need, None) or (None, why not)."""
     import csv, glob, shutil, subprocess, tempfile
     if os.environ.get("RAYHS_BENCH_NO_LIVE_PMC"):
         return None, "live counter passes switched off (RAYHS_BENCH_NO_LIVE_PMC)"

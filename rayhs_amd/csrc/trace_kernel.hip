@@ -48,6 +48,9 @@
 //   * Everything that enters a result is fp64 like the reference.  Built twice: "exact"
 //     (-ffp-contract=off, same operations as the reference/oracle, the default) and "fast" (fused
 //     multiply-add allowed, RAYHS_FLAG_FMA).
+//   * What bounds it is instruction throughput (profiles/r05/micro/issue_rates.txt): a CU's ONE scalar unit
+//     (1.05 cycles per scalar instruction of any of its 16 waves) and its four vector pipes (2 cycles per wave64 fp32 add / mul / fma,
+//     4 per fp64 add / mul / fma, integer, compare, select, convert; 16 per fp64 rcp / rsq / sqrt) are both about two thirds busy.
 //   * To run 4 waves per SIMD the kernel must fit 128 VGPRs and 40 KiB of LDS per workgroup: the
 //     shading context of a hit (p, n, cd, A and, when LDS has room, the light term) lives in LDS; the
 //     view direction and the continuation frames of suspended irradiance calls in a global workspace
@@ -514,8 +517,8 @@ struct Tracer {
     static __device__ __forceinline__ bool met(float tn, float tf, float limf) { return fmaxf(tn, 0.0f) <= fminf(tf, limf); }
 
     // slab test of one child box: t = plane * A + B (A = 1/d, B = -o/d), one fused multiply-add per plane.  (Two v_fma_f32, not
-    // one v_pk_fma_f32: the packed form wants every coefficient twice -- 12 registers instead of 6 across the walks -- and at 4
-    // waves per SIMD it issues at the fp64 rate, three times slower than two plain ones: profiles/r04/micro/issue_rates.txt.
+    // one v_pk_fma_f32: the packed form wants every coefficient twice -- 12 registers instead of 6 across the walks -- and buys no
+    // throughput for it: it occupies the SIMD for 4.1 cycles, two plain ones for 2 x 2.2 (profiles/r05/micro/issue_rates.txt).
     // 62 -> 42 spilled registers, dragon frame -1.6 %, dragon_low -2.3 %: profiles/r04/experiments/scalar_fma_boxes.log.)
     // Culling only: the stored boxes are inflated far beyond the fp32 rounding of these operations (abi.cpp).
     typedef float f2 __attribute__((ext_vector_type(2)));

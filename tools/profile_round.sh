@@ -14,7 +14,7 @@ export RAYHS_BENCH_IN_FLIGHT=1
 rm -rf ${pre}_trace ${pre}_pmc_* ${pre}_bench.* ${pre}_trace_bench.json
 mkdir -p $out
 steps=30; [ "$wl" = dragon4k ] && steps=8
-sha256sum rayhs_amd/csrc/trace_kernel.hip rayhs_amd/csrc/device_scene.h rayhs_amd/csrc/abi.cpp | sha256sum | cut -d' ' -f1 > ${pre}_kernel_source.sha256
+python3 -c "import bench; print(bench.kernel_source_sha256())" > ${pre}_kernel_source.sha256   # (over the code of trace_kernel.hip, device_scene.h, abi.cpp: comments stripped)
 timeout -k 10 500 python3 bench.py --workload $wl --steps $steps --warmup 3 > ${pre}_bench.json 2> ${pre}_bench.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d ${pre}_trace -- python3 bench.py --workload $wl --steps $steps --warmup 3 --cpu-seconds 0 --no-4k > ${pre}_trace_bench.json 2>/dev/null || exit 2
 pmc() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d ${pre}_pmc_$name -- python3 bench.py --workload $wl --steps 3 --warmup 1 --cpu-seconds 0 --no-4k > /dev/null 2>&1; }
