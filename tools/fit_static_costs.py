@@ -1,6 +1,7 @@
 """Fit the weights of the static first-frame tile estimate (rayhs_static_costs) to measured chunk times (development aid).
 
-    GPU box (a -DRAYHS_DEV_KNOBS build):   RAYHS_LIB=build_exp/cur/librayhs_hip.so python tools/fit_static_costs.py collect
+    GPU box (a -DRAYHS_DEV_KNOBS build WITH profiles/r05/experiments/static_cost_features.patch applied: the shipped estimate computes
+    four of the eight features only and has no feature dump):   RAYHS_LIB=build_exp/cur/librayhs_hip.so python tools/fit_static_costs.py collect
         -> profiles/r05/experiments/tile_features/tile_features_<workload>.npz: per 8x8 tile the longest chunk time a steady-state frame measured (100 MHz ticks) and
            the estimate's eight raw features (RAYHS_DUMP_TILE_COSTS + RAYHS_DUMP_RAW_FEATURE=8)
     anywhere:                              python tools/fit_static_costs.py fit
