@@ -762,6 +762,9 @@ def test_first_frame_static_order_is_a_permutation_that_leads_with_the_slow_tile
         r.ray_trace(spp=4, out_format=L.OUT_F32)
         recs.append(r.tile_order())
     assert r.ray_trace(spp=4, flags=COUNTING, row0=0, row1=8)[1]["pixels"] == 1920 * 8 and len(r.tile_order()[0]) == 0  # (a counting run: scan order)
+    r.ray_trace(spp=4, out_format=L.OUT_F32)
+    small = np.zeros(16, dtype=np.int32)   # a buffer that cannot hold the order is refused, not overrun
+    assert L.load().rayhs_scene_tile_order(r._h, small.ctypes.data_as(C.POINTER(C.c_int32)), 16, None) == L.ERR_INVALID and not small.any()
     r.close()
     n = 240 * 135
     assert recs[0][1] is True and recs[1][1] is False        # static estimate first, measured chunk times second

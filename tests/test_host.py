@@ -84,6 +84,15 @@ def test_loader_refuses_a_library_of_another_abi_version_or_layout(monkeypatch):
     assert L.load().rayhs_abi_version() == 4
 
 
+def test_diagnostic_entry_points_refuse_a_null_scene_without_touching_a_device():
+    # rayhs_scene_capture_tile_order / rayhs_scene_tile_order (ABI 4) validate their handle first; rayhs_config_reload only re-reads
+    # the environment: none of them needs a GPU
+    lib = L.load()
+    assert lib.rayhs_scene_capture_tile_order(None, 1) == L.ERR_INVALID
+    assert lib.rayhs_scene_tile_order(None, None, 0, None) == L.ERR_INVALID and b"NULL" in lib.rayhs_last_error()
+    lib.rayhs_config_reload()
+
+
 def test_sampler_matches_oracle_definition():
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["sampler"]
     for seed, pixel, sample, dim, spp, hexv in gold:
