@@ -32,6 +32,7 @@ Extra objects on the JSON line:
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -75,7 +76,12 @@ def _code_only(text):
     out, i, n = [], 0, len(text)
     while i < n:
         c = text[i]
-        if c == '"' or c == "'":                       # a literal: copied whole
+        # a literal: copied whole.  An apostrophe only opens a CHARACTER literal when it cannot be a C++14 digit separator (1'000'000) or
+        # an apostrophe of unquoted preprocessor text (#error don't): the character before it is not alphanumeric and the literal closes within
+        # a few characters on the same line; any other apostrophe is copied as it stands and the scanner stays in step.
+        is_char = (c == "'" and not (i > 0 and (text[i - 1].isalnum() or text[i - 1] == "_"))
+                   and re.match(r"'(\\.[^'\n]{0,8}|[^'\\\n])'", text[i:i + 12]) is not None)
+        if c == '"' or is_char:
             j = i + 1
             while j < n and text[j] != c:
                 j += 2 if text[j] == "\\" else 1
@@ -276,12 +282,16 @@ def main():
     backend = os.environ.get("RAYHS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        ranks_seen = dist.get_world_size()
+        if ranks_seen != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {ranks_seen} ranks")
 
     def run_workload(workload, steps, warmup, want_first_frame=True):
         """Set-up, warm-up and the timed loop of one workload; returns its local variables."""
@@ -387,6 +397,21 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+        # N > 1: what the collective layer saw, for whoever reads the line of a scaling run -- every rank's mean trace-kernel time and the
+        # time of one gather + assembly by itself (three in a row, nothing else in flight; outside the timed region)
+        kernel_ms_per_rank, gather_ms = [kernel_ms], None
+        if world > 1:
+            km = torch.zeros(world, dtype=torch.float64, device=dev)  # (an all-reduce of one-hot rows: every backend the rehearsals use has it for device tensors)
+            km[rank] = kernel_ms
+            dist.all_reduce(km)
+            kernel_ms_per_rank = km.tolist()
+            sync_all()
+            tg = time.perf_counter()
+            for _ in range(3):
+                with torch.cuda.stream(streams[0]):
+                    slots[0].gather()
+            sync_all()
+            gather_ms = (time.perf_counter() - tg) / 3 * 1e3
 
         # The first frame of a handle -- the only frame a one-shot `rayhs -oX scene.json` ever renders (src/RayHs.hs:215-234)
         # -- has no measured chunk times to order its tiles by and uses the static estimate instead.  Timed (untimed for
@@ -487,7 +512,8 @@ def main():
         binding = None
         if valu and scalar:
             binding = ("valu", valu) if valu["frac"] >= scalar["frac"] else ("scalar-issue", scalar)
-        roofline = {"bound": binding[0] if binding else "scalar-issue", "achieved": binding[1]["achieved"] if binding else None,
+        # (without instruction counts -- no committed profile of this kernel source and no live passes -- no roof is named: `bound` is null)
+        roofline = {"bound": binding[0] if binding else None, "achieved": binding[1]["achieved"] if binding else None,
                     "peak": binding[1]["peak"] if binding else N_CUS * MAX_CLOCK_GHZ, "unit": binding[1]["unit"] if binding else "G CU-cycles/s",
                     "frac": binding[1]["frac"] if binding else None,
                     "traffic": ctr["traffic"] if ctr else None,
@@ -527,6 +553,10 @@ def main():
             "mpixels_per_s": w * h * args.steps / dt / 1e6,
             "rays_per_frame": rays_frame, "reference_rays_per_frame": reference_rays_frame,
             "kernel_ms_rank0": kernel_ms, "first_frame_ms": first_frame_ms,
+            # what the collective layer saw (N > 1: the backend torch.distributed really runs -- "nccl" is RCCL on ROCm -- the ranks of its
+            # process group, every rank's mean trace-kernel time, one gather + assembly by itself)
+            "distributed": {"backend": (dist.get_backend() if world > 1 else None), "ranks_seen": ranks_seen, "devices_visible": torch.cuda.device_count(),
+                            "kernel_ms_per_rank": m["kernel_ms_per_rank"], "gather_ms": m["gather_ms"]},
             "north_star_4k": also_4k, "trace_launches_after_timed": launches_after_timed,
             "verified_against_single_rank": verified,
             "verified_against_oracle": {"whole_frame_sha256_equals_oracle_digest": golden_ok, "rows_against_live_oracle": None},

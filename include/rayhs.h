@@ -189,9 +189,11 @@ int rayhs_device_count(void);
 
 /* The library reads its RAYHS_* environment switches ONCE, when it is loaded (never on the launch path): scheduling policy
  * that cannot change a pixel -- RAYHS_SCAN_ORDER, RAYHS_NO_STATIC_ORDER, RAYHS_REORDER_EVERY=n, RAYHS_NO_WAVE_RESOLVE,
- * RAYHS_ROUND_ROBIN_STRIPES, RAYHS_LPT_STRIPES, RAYHS_MULTI_PARALLEL_CREATE, RAYHS_MULTI_SERIAL -- and the stderr diagnostics
- * RAYHS_DEBUG_COUNTERS, RAYHS_DEBUG_TIMING.  A host that changes its environment afterwards calls this to have them read again;
- * not while another thread is inside the library.  (Development knobs -- stack cap, workgroups per CU, dumps, BVH leaf size --
+ * RAYHS_ROUND_ROBIN_STRIPES, RAYHS_LPT_STRIPES, RAYHS_MULTI_PARALLEL_CREATE (one thread per device at rayhs_multi_create; opt-in),
+ * RAYHS_MULTI_SERIAL_CREATE (overrides it: devices brought up one after the other, the default), RAYHS_MULTI_SERIAL -- and the stderr
+ * diagnostics RAYHS_DEBUG_COUNTERS, RAYHS_DEBUG_TIMING.  A host that changes its environment afterwards calls this to have them read
+ * again; safe while other threads are inside the library (they keep the snapshot of the switches they are reading: the new one is
+ * swapped in, never written over the old).  (Development knobs -- stack cap, workgroups per CU, dumps, BVH leaf size --
  * exist only in builds made with -DRAYHS_DEV_KNOBS.)  ABI version 4. */
 void rayhs_config_reload(void);
 

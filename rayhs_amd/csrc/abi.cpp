@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -97,9 +98,14 @@ static Config read_config() {
 #endif
     return c;
 }
-static Config g_cfg = read_config();
-// Not to be called while another thread is inside the library (it replaces the switches every entry point reads).
-extern "C" void rayhs_config_reload(void) { g_cfg = read_config(); }
+// The switches live in an immutable snapshot behind a shared pointer that rayhs_config_reload() SWAPS (atomically): an entry point that is
+// running on another thread -- a rayhs_multi worker, say -- keeps reading the snapshot it took, whole and alive, while the next mention
+// sees the new one.  (It was one plain global struct that reload overwrote in place under every reader.)  Every `g_cfg.x` below is
+// a read through a snapshot held for the length of that expression; strings are copied out before they are used.
+static std::shared_ptr<const Config> g_cfg_snapshot = std::make_shared<const Config>(read_config());
+static std::shared_ptr<const Config> config_snapshot() { return std::atomic_load(&g_cfg_snapshot); }
+#define g_cfg (*config_snapshot())
+extern "C" void rayhs_config_reload(void) { std::atomic_store(&g_cfg_snapshot, std::shared_ptr<const Config>(std::make_shared<const Config>(read_config()))); }
 
 // uint64 per launch: 8 range counters, each alone on its own 128-byte L2 line (stride 16), then -- on a 128-byte line of their own --
 // the 8 "range is dry" flags.  (At a 64-byte stride two counters shared an L2 line, and so did the flags, which are read at
@@ -843,6 +849,9 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
     if (!d_out) return set_error(RAYHS_ERR_INVALID, "d_out is NULL");
     if ((variant == 1 || variant == 2) && !d_counters) return set_error(RAYHS_ERR_INVALID, "RAYHS_FLAG_COUNT needs d_counters");
     HIP_TRY(hipSetDevice(s->device));
+    // rayhs_scene_tile_order reports the order of the LAST launch: a launch that hands out no tiles (an empty row selection), or fails
+    // before it has an order, must not leave the previous frame's order standing as its own
+    if (s->capture_order) { s->captured_tiles = 0; s->captured_static = 0; }
     if (dp.n_tiles == 0) {  // nothing to trace: the caller's events still get recorded, so that it can wait on / time them
         if (e0) HIP_TRY(hipEventRecord(e0, st));
         if (e1) HIP_TRY(hipEventRecord(e1, st));
@@ -891,7 +900,8 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
         std::vector<float> h((size_t)dp.n_tiles);
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h.data(), s->cost_dev, h.size() * sizeof(float), hipMemcpyDeviceToHost));
-        if (FILE *f = std::fopen(g_cfg.dump_tile_costs.c_str(), "ab")) {
+        const std::string dump_path = g_cfg.dump_tile_costs;
+        if (FILE *f = std::fopen(dump_path.c_str(), "ab")) {
             int hdr[4] = {dp.n_tiles, dp.tiles_x, dp.spp, 0};
             std::fwrite(hdr, sizeof hdr, 1, f);
             std::fwrite(h.data(), sizeof(float), h.size(), f);
@@ -1011,7 +1021,8 @@ extern "C" int rayhs_render(const rayhs_scene *s, const rayhs_camera *cam, const
     }
     HIP_TRY(hipStreamSynchronize(nullptr));
 #if defined(RAYHS_DEV_KNOBS) && (defined(RAYHS_PROFILE_TIME) || defined(RAYHS_WAVE_ENDS))
-    if (const char *path = g_cfg.dump_wave_ends.empty() ? nullptr : g_cfg.dump_wave_ends.c_str()) {  // development (tools/wave_ends.py): per wave (start, end, last chunk drawn at, chunks), 100 MHz ticks
+    const std::string wave_ends_path = g_cfg.dump_wave_ends;
+    if (const char *path = wave_ends_path.empty() ? nullptr : wave_ends_path.c_str()) {  // development (tools/wave_ends.py): per wave (start, end, last chunk drawn at, chunks), 100 MHz ticks
         std::vector<unsigned long long> w((size_t)s->cu_count * 16 * 4);  // (4 workgroups of 4 waves per CU)
         HIP_TRY(hipMemcpy(w.data(), s->frames, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         if (FILE *f = std::fopen(path, "wb")) { std::fwrite(w.data(), sizeof(unsigned long long), w.size(), f); std::fclose(f); }

@@ -624,6 +624,11 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["verified_against_single_rank"] is True
+    # the line says what the collective layer saw: backend, ranks of the process group, every rank's kernel time, the gather by itself
+    d = out["distributed"]
+    assert d["backend"] == "gloo" and d["ranks_seen"] == 2 and len(d["kernel_ms_per_rank"]) == 2
+    assert all(t > 0 for t in d["kernel_ms_per_rank"]) and d["gather_ms"] > 0
+    assert abs(d["kernel_ms_per_rank"][0] - out["kernel_ms_rank0"]) < 1e-9
     assert out["metric"] == "Mrays/s" and out["value"] > 0 and out["scaling"] == "strong"
     assert out["rays_per_frame"] > 1920 * 1080 * 4
     # the extra leg on the 4K / 64 spp frame (BASELINE configs[4]): two ranks' stripes gathered, whole frame == oracle digest

@@ -434,3 +434,38 @@ def test_committed_profiles_carry_the_two_roofs_bench_py_prices_with():
     if d.get("kernel_source_sha256") != bench.kernel_source_sha256():
         pytest.skip("the committed profile was taken on another kernel source: bench.py will count instructions live (rocprofv3 --pmc child runs); "
                     "re-run tools/profile_round.sh + tools/summarize_profiles.py before the round ends")
+
+
+def test_a_profiled_bench_run_never_starts_a_profiler_of_its_own():
+    # tools/*.sh: every `rocprofv3 ... -- python3 bench.py` line must run with the live counter passes switched off (an exported
+    # RAYHS_BENCH_NO_LIVE_PMC=1 that is still in force at that line, or --pmc-child on the line itself): bench.py otherwise starts
+    # three `rocprofv3 --pmc` children from inside a process that is already being profiled whenever no committed profile matches the
+    # kernel source -- the normal case while a round's profiles are being taken.
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tools = os.path.join(root, "tools")
+    checked = 0
+    for name in sorted(os.listdir(tools)):
+        if not name.endswith(".sh"):
+            continue
+        guarded = False   # an `export RAYHS_BENCH_NO_LIVE_PMC=1` seen so far in this script
+        for ln in open(os.path.join(tools, name)):
+            code = ln.split("#")[0]
+            if re.search(r"\bexport\s+RAYHS_BENCH_NO_LIVE_PMC=1\b", code):
+                guarded = True
+            if re.search(r"\bexport\s+RAYHS_BENCH_NO_LIVE_PMC=\s*$", code) or re.search(r"\bunset\s+RAYHS_BENCH_NO_LIVE_PMC\b", code):
+                guarded = False
+            if "rocprofv3" in code and re.search(r"(?<![A-Za-z_])bench\.py", code):   # (not tools/kbench.py: that one starts no profiler)
+                checked += 1
+                inline_off = re.search(r"RAYHS_BENCH_NO_LIVE_PMC=(\s|$)", code.split("rocprofv3")[0]) is not None
+                assert ("--pmc-child" in code or (guarded and not inline_off)), f"tools/{name}: profiled bench.py without the guard: {ln.strip()}"
+    assert checked >= 2   # the --kernel-trace run and the pmc() passes of tools/profile_round.sh
+
+
+def test_kernel_source_hash_ignores_comments_but_not_code_behind_an_apostrophe():
+    import bench
+    a = "int a = 1'000'000; // c\nchar q = '\\''; char r = 'x'; /* y */ const char *s = \"it's // not\";\n#error don't do this // gone\nint z = 2;\n"
+    got = bench._code_only(a)
+    assert got == "int a = 1'000'000;\nchar q = '\\''; char r = 'x';  const char *s = \"it's // not\";\n#error don't do this\nint z = 2;\n"
+    # code behind a digit separator or a stray apostrophe still counts: changing it changes what is hashed
+    assert bench._code_only(a.replace("int z = 2;", "int z = 3;")) != got
+    assert bench._code_only("x = 1'0; // a\ny = 2;\n") != bench._code_only("x = 1'0; // a\ny = 3;\n")

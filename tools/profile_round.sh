@@ -11,11 +11,16 @@ out=gpurun_out
 pre=$out/${tag}_${wl}
 export TMPDIR=/tmp
 export RAYHS_BENCH_IN_FLIGHT=1
+# a run that is itself under rocprofv3 must never start a profiler of its own (bench.py's live counter passes are for un-profiled runs on a
+# kernel source no committed profile matches -- the normal case while a round is being profiled): summarize_profiles.py derives the roofs from
+# the passes below anyway
+export RAYHS_BENCH_NO_LIVE_PMC=1
 rm -rf ${pre}_trace ${pre}_pmc_* ${pre}_bench.* ${pre}_trace_bench.json
 mkdir -p $out
 steps=30; [ "$wl" = dragon4k ] && steps=8
 python3 -c "import bench; print(bench.kernel_source_sha256())" > ${pre}_kernel_source.sha256   # (over the code of trace_kernel.hip, device_scene.h, abi.cpp: comments stripped)
-timeout -k 10 500 python3 bench.py --workload $wl --steps $steps --warmup 3 > ${pre}_bench.json 2> ${pre}_bench.err || exit 1
+# (the one un-profiled run of this script may count its instructions itself: its children are the only profiler sessions around it)
+RAYHS_BENCH_NO_LIVE_PMC= timeout -k 10 500 python3 bench.py --workload $wl --steps $steps --warmup 3 > ${pre}_bench.json 2> ${pre}_bench.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d ${pre}_trace -- python3 bench.py --workload $wl --steps $steps --warmup 3 --cpu-seconds 0 --no-4k > ${pre}_trace_bench.json 2>/dev/null || exit 2
 pmc() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d ${pre}_pmc_$name -- python3 bench.py --workload $wl --steps 3 --warmup 1 --cpu-seconds 0 --no-4k > /dev/null 2>&1; }
 pmc fetch FETCH_SIZE || exit 3
