@@ -99,10 +99,10 @@ def _code_only(text):
 
 def kernel_source_sha256():
     """Identity of the kernel being benchmarked: what tools/profile_round.sh records next to its counters.  Taken over the CODE of the
-    three files (comments and blank lines stripped): correcting a comment must not orphan the committed profiles."""
+    four files (comments and blank lines stripped): correcting a comment must not orphan the committed profiles."""
     import hashlib
     lines = []
-    for f in ("rayhs_amd/csrc/trace_kernel.hip", "rayhs_amd/csrc/device_scene.h", "rayhs_amd/csrc/abi.cpp"):
+    for f in ("rayhs_amd/csrc/trace_kernel.hip", "rayhs_amd/csrc/device_scene.h", "rayhs_amd/csrc/short_div.h", "rayhs_amd/csrc/abi.cpp"):
         lines.append(f"{hashlib.sha256(_code_only(open(os.path.join(ROOT, f)).read()).encode()).hexdigest()}  {f}\n")
     return hashlib.sha256("".join(lines).encode()).hexdigest()
 

@@ -121,6 +121,7 @@ struct rayhs_scene {
     DScene d{};
     std::vector<void *> allocs;
     int tree_depth = -1;  // deepest level of the reference trees over all meshes
+    bool huge_coords = false;  // a vertex coordinate beyond 1e90: every frame of this scene goes through the exhaustive kernel (prepare_launch)
     int fast_depth = 0;   // deepest inner node of the fast BVHs
     // launch workspace (grow-only; steady-state renders allocate nothing)
     mutable double *frames = nullptr;
@@ -327,6 +328,7 @@ struct PackedScene {
     int plane_axis_end[3] = {0, 0, 0};
     int n_objects = 0, n_lights = 0, n_nodes = 0, n_tris = 0;
     int tree_depth = -1, fast_depth = 0;
+    bool huge_coords = false;   // some vertex coordinate is finite and beyond 1e90 in magnitude (see prepare_launch)
 };
 
 static int pack_scene(const rayhs_scene_desc *desc, PackedScene &pk) {
@@ -526,15 +528,19 @@ static int pack_scene(const rayhs_scene_desc *desc, PackedScene &pk) {
     std::vector<DLight> &lights = pk.lights; lights.assign((size_t)d.n_lights, DLight());
     for (int i = 0; i < d.n_lights; i++) {
         DLight &l = lights[(size_t)i];
-        l.kind = d.light_kind[i]; l.pad = 0;
+        l.kind = d.light_kind[i];
         for (int c = 0; c < 3; c++) { l.v[c] = d.light_vec[3 * i + c]; l.c[c] = d.light_color[3 * i + c]; }
         l.radius = d.light_radius[i];
+        // a point light with an ordinary radius: the kernel may compute its falloff without the divisions' range fix-ups (trace_kernel.hip, rcp_in_range)
+        l.short_ok = (l.kind == RAYHS_LIGHT_POINT && l.radius >= 1e-60 && l.radius <= 1e60) ? 1 : 0;
     }
     pk.texels.clear();
     if (d.n_texels > 0) pk.texels.assign(d.texels, d.texels + 3 * (size_t)d.n_texels);
 
     pk.n_objects = d.n_objects; pk.n_lights = d.n_lights; pk.n_nodes = d.n_nodes; pk.n_tris = d.n_tris;
     pk.tree_depth = tree_depth; pk.fast_depth = fast_depth;
+    for (size_t i = 0; i < 9 * (size_t)d.n_tris && !pk.huge_coords; i++)
+        pk.huge_coords = std::isfinite(d.tri_pos[i]) && std::fabs(d.tri_pos[i]) > 1e90;
     return RAYHS_OK;
 }
 
@@ -557,6 +563,7 @@ static int upload_scene(const PackedScene &pk, int device, rayhs_scene **out) {
     s->cu_count = prop.multiProcessorCount;
     s->tree_depth = pk.tree_depth;
     s->fast_depth = pk.fast_depth;
+    s->huge_coords = pk.huge_coords;
     auto fail = [&](int code) { rayhs_scene_destroy(s); return code; };
     if ((rc = upload(s, pk.nodes, &s->d.nodes))) return fail(rc);
     if ((rc = upload(s, pk.tris, &s->d.tris))) return fail(rc);
@@ -711,6 +718,11 @@ static int prepare_launch(const rayhs_scene *s, const rayhs_camera *cam, const r
     // kernel variants: 0 fast (16-bit stack entries, < 65536 BVH nodes), 3 fast (32-bit entries),
     // 1 counting, 2 exhaustive + counting (the reference's tree)
     variant = (p->flags & RAYHS_FLAG_EXHAUSTIVE) ? 2 : (p->flags & RAYHS_FLAG_COUNT) ? 1 : (s->d.n_fnodes < 65536 && s->d.n_nodes < 65536 ? 0 : 3);
+    // A scene with finite vertex coordinates beyond 1e90 is rendered by the exhaustive kernel (the reference's own tree and fp64 boxes, the
+    // compiler's full IEEE divisions), whatever was asked for: the fast walks' triangle tests take 1 / det without the division's range
+    // fix-ups, which is the same double only while |det| < 2^1022 -- certain for coordinates below 1e90 and rays below 1e30 (begin()), not
+    // beyond.  Same pixels (the exhaustive and the fast kernels agree bit for bit), slower, and nobody renders such a scene.
+    if (s->huge_coords) variant = 2;
     dp.stack_cap = std::max(std::max(s->tree_depth, s->fast_depth) + 2, 4);  // either tree may be walked (trace_kernel.hip)
 #ifdef RAYHS_DEV_KNOBS
     if (g_cfg.stack_cap > 0) dp.stack_cap = std::max(4, g_cfg.stack_cap);  // development knob (UNSAFE below the tree depth: exists only in -DRAYHS_DEV_KNOBS builds)
@@ -847,6 +859,7 @@ static int launch(const rayhs_scene *s, const rayhs_camera *cam, const rayhs_ren
     int rc = prepare_launch(s, cam, p, sl, dc, dp, variant, exact, grid, lds);
     if (rc) return rc;
     if (!d_out) return set_error(RAYHS_ERR_INVALID, "d_out is NULL");
+    if (variant == 2 && !d_counters && s->huge_coords) d_counters = (uint64_t *)s->counters;  // (the exhaustive kernel always counts: into the handle's own buffer then)
     if ((variant == 1 || variant == 2) && !d_counters) return set_error(RAYHS_ERR_INVALID, "RAYHS_FLAG_COUNT needs d_counters");
     HIP_TRY(hipSetDevice(s->device));
     // rayhs_scene_tile_order reports the order of the LAST launch: a launch that hands out no tiles (an empty row selection), or fails

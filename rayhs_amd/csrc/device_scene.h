@@ -91,7 +91,8 @@ struct DObject {  // Material (src/Material.hs:13-19) + ColorMap (src/ColorMap.h
 struct DObjectHot { int32_t mat_kind, cmap_kind, tex_w, tex_h; double c1[3], ior, fr, one_m_r0; };
 static_assert(sizeof(DObjectHot) == 64, "the hot head of DObject is one 64-byte fetch");
 struct DLight {   // src/Light.hs:8-10
-    int32_t kind, pad;
+    int32_t kind;
+    int32_t short_ok;   // point light whose radius lies in [1e-60, 1e60]: its falloff may be computed without the divisions' range fix-ups (trace_kernel.hip, rcp_in_range)
     double v[3], c[3], radius;
 };
 

@@ -67,6 +67,7 @@
 #include <type_traits>
 
 #include "device_scene.h"
+#include "short_div.h"
 
 #ifndef RAYHS_KERNEL_SUFFIX
 #define RAYHS_KERNEL_SUFFIX fast
@@ -155,6 +156,13 @@ DEV V3 reflect(V3 v, V3 n) { return sub(v, scl(2 * dot(v, n), n)); }        // s
 // Haskell Ord Double: min x y = if x <= y then x else y; max x y = if x <= y then y else x
 DEV double hs_min(double x, double y) { return x <= y ? x : y; }
 DEV double hs_max(double x, double y) { return x <= y ? y : x; }
+
+// (rcp_in_range, div_in_range, sqrt_in_range: short_div.h -- IEEE division and square root without their range fix-ups, where the range is known)
+#ifdef RAYHS_NO_SHORT_DIV
+constexpr bool kShortDiv = false;
+#else
+constexpr bool kShortDiv = true;
+#endif
 
 constexpr double kEps = 0.000001;                 // src/Geometry.hs:31-32
 constexpr double kPiInv = 1 / 3.141592653589793;  // src/Math.hs:12-13
@@ -444,11 +452,12 @@ struct Tracer {
     }
 
     // triangleIntersection (src/Mesh.hs:59-72)
-    template <class TR> __device__ __forceinline__ bool tri_test(const TR &tr, const Ray &r, double &t, double &u, double &v) {
+    // SHORT (the fast BVH's walks only): 1 / det by rcp_in_range -- the same double wherever the lane is not rejected by |det| < eps
+    template <bool SHORT = false, class TR> __device__ __forceinline__ bool tri_test(const TR &tr, const Ray &r, double &t, double &u, double &v) {
         V3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
         V3 p = cross(r.d, e2);
         double det = dot(e1, p);
-        double idet = 1 / det;
+        double idet = (SHORT && kShortDiv) ? rcp_in_range(det) : 1 / det;
         V3 t0 = sub(r.o, ld3(tr.p0));
         u = idet * dot(t0, p);
         V3 q = cross(t0, e1);
@@ -477,7 +486,7 @@ struct Tracer {
         V3 e1 = ld3(tr.e1), e2 = ld3(tr.e2);
         V3 p = cross(r.d, e2);
         double det = dot(e1, p);
-        double idet = 1 / det;
+        double idet = kShortDiv ? rcp_in_range(det) : 1 / det;   // (only the packet walk of the fast BVH uses the mask form)
         V3 t0 = sub(r.o, ld3(tr.p0));
         u = idet * dot(t0, p);
         V3 q = cross(t0, e1);
@@ -899,6 +908,10 @@ struct Tracer {
                 int cur = me.froot, sp = 0;
                 while (true) {
                     LOOP_TICK(40);
+#ifdef RAYHS_PROBE_NODE_FETCH2  // development: what a packet visit's node fetch costs -- a second, DEPENDENT scalar fetch (of the same line: a scalar-cache
+                    // hit, ~115 cycles) in front of the real one; profiles/r06/experiments/packet_node_fetch_twice.log
+                    cur += *(cptr<int>)((unsigned long long)fnodes + (unsigned long long)((unsigned)cur * (unsigned)sizeof(FNode)) + offsetof(FNode, pad_));  // (pad_ is 0)
+#endif
                     const auto &nd = crec(fnodes, cur);
                     const int c0 = nd.c0, c1 = nd.c1;
                     float tn0, tn1;
@@ -1056,7 +1069,7 @@ struct Tracer {
                         if (COUNT) cnt.c[CNT_TRIS]++;
                         LOOP_TICK(30);
                         double t, u, v;
-                        if (tri_test(tr, r, t, u, v)) {
+                        if (tri_test<true>(tr, r, t, u, v)) {
                             bool admitted = true;
                             if (u < kEdgeBand || v < kEdgeBand || (u + v) > 1 - kEdgeBand)
                                 admitted = reference_path_admits(SC.nodes, rec(SC.fattrs, k).leaf_node, r.o, r.d);
@@ -1507,10 +1520,25 @@ static __device__ __forceinline__ void trace_body() {
                         if (L.kind == 0) { ld = ld3(L.v); lc = ld3(L.c); q_point = false; q_d2 = 0; q_dist = __builtin_inf(); }
                         else {
                             V3 dv = sub(ld3(L.v), c_p);
-                            double d = sqrt(dot(dv, dv));
-                            double den = 1.0 + d / L.radius;
-                            double falloff = 1.0 / (den * den);
-                            ld = scl(1 / d, dv);
+                            const double d2 = dot(dv, dv);
+                            // The root and the three divisions without their range fix-ups (rcp_in_range above: the same doubles) when every
+                            // lane here has 2^-399 <= d2 < 2^399 (one subtraction and one comparison on the high word: d in [2^-200, 2^200))
+                            // and a light whose radius the launcher found in [1e-60, 1e60] (DLight.short_ok): then den in [1, 2^400],
+                            // den^2 < 2^801, and no operand or quotient comes near the ranges the fix-ups exist for.
+                            const bool in_range = kShortDiv && ((unsigned)__double2hiint(d2) - 0x27000000u) < (0x58e00000u - 0x27000000u) && L.short_ok != 0;
+                            double d, falloff, inv_d;
+                            if (kShortDiv && __ballot(!in_range) == 0ull) {
+                                d = sqrt_in_range(d2);
+                                const double den = 1.0 + div_in_range(d, L.radius);
+                                falloff = rcp_in_range(den * den);
+                                inv_d = rcp_in_range(d);
+                            } else {
+                                d = sqrt(d2);
+                                const double den = 1.0 + d / L.radius;
+                                falloff = 1.0 / (den * den);
+                                inv_d = 1 / d;
+                            }
+                            ld = scl(inv_d, dv);
                             lc = scl(falloff, ld3(L.c));
                             q_point = true; q_dist = d;
                         }

@@ -18,7 +18,7 @@ export RAYHS_BENCH_NO_LIVE_PMC=1
 rm -rf ${pre}_trace ${pre}_pmc_* ${pre}_bench.* ${pre}_trace_bench.json
 mkdir -p $out
 steps=30; [ "$wl" = dragon4k ] && steps=8
-python3 -c "import bench; print(bench.kernel_source_sha256())" > ${pre}_kernel_source.sha256   # (over the code of trace_kernel.hip, device_scene.h, abi.cpp: comments stripped)
+python3 -c "import bench; print(bench.kernel_source_sha256())" > ${pre}_kernel_source.sha256   # (over the code of trace_kernel.hip, device_scene.h, short_div.h, abi.cpp: comments stripped)
 # (the one un-profiled run of this script may count its instructions itself: its children are the only profiler sessions around it)
 RAYHS_BENCH_NO_LIVE_PMC= timeout -k 10 500 python3 bench.py --workload $wl --steps $steps --warmup 3 > ${pre}_bench.json 2> ${pre}_bench.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d ${pre}_trace -- python3 bench.py --workload $wl --steps $steps --warmup 3 --cpu-seconds 0 --no-4k > ${pre}_trace_bench.json 2>/dev/null || exit 2
