@@ -578,7 +578,7 @@ static int upload_scene(const PackedScene &pk, int device, rayhs_scene **out) {
     if ((rc = upload(s, pk.lights, &s->d.lights))) return fail(rc);
     if ((rc = upload(s, pk.texels, &s->d.texels))) return fail(rc);
     s->d.n_planes = (int)pk.planes.size();
-    for (int a = 0; a < 3; a++) s->d.plane_axis_end[a] = pk.plane_axis_end[a];
+    for (int a = 0; a < 3; a++) s->d.plane_axis_end[a] = (int32_t)((uint32_t)pk.plane_axis_end[a] * (uint32_t)sizeof(DPlane));   // (byte offsets: what the query loop counts in)
     s->d.n_spheres = (int)pk.spheres.size();
     s->d.sphere_occluders = 0;
     for (const DSphere &sp : pk.spheres) s->d.sphere_occluders += sp.occluder ? 1 : 0;

@@ -104,8 +104,9 @@ struct DScene {
     int32_t n_planes, n_spheres;
     int32_t sphere_occluders;  // spheres that can occlude (not Emmit): with none, a round of shadow queries skips the sphere loop
     int32_t n_lights;
-    // planes are stored grouped: [0, plane_axis_end[0]) have a normal along x, [.., [1]) along y, [.., [2]) along z, the
-    // rest are in general position (the query loop runs a body specialised per group; ties go by object index)
+    // planes are stored grouped: the records in [0, plane_axis_end[0]) have a normal along x, [.., [1]) along y, [.., [2]) along z, the
+    // rest are in general position (the query loop runs a body specialised per group; ties go by object index).  BYTE offsets into
+    // `planes` (multiples of sizeof(DPlane)): the loop counts in them
     int32_t plane_axis_end[3];
     int32_t n_meshes;
     const DMesh *meshes;

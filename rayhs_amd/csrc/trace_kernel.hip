@@ -312,7 +312,8 @@ enum : int { ST_HIT = 1, ST_SHADOW, ST_EXIT, ST_DONE };
 // frame kinds
 enum : int { FR_PLASTIC = 0, FR_MIRROR, FR_TRANS_WAIT_RADIANCE, FR_TRANS_WAIT_SPEC };
 // query kinds
-enum : int { Q_NONE = 0, Q_CLOSEST, Q_SHADOW };
+enum : int { Q_NONE = 0, Q_CLOSEST, Q_SHADOW, Q_SHADOW_POINT };  // (a shadow query towards a point light is a kind of its own: a yes/no carried beside the kind
+                                                                // across the shading sections cost a wave mask and three scalar instructions at every join)
 
 #ifdef RAYHS_PROFILE_LOOPS
 constexpr int kCounterSlots = CNT_SLOTS_DEV;  // + (active lanes, wave executions) pairs of the shading sections and query loops
@@ -379,7 +380,7 @@ struct Tracer {
     bool bref;  // btri indexes the reference-order arrays (hit found by the reference tree), else the BVH-order ones
     bool occ;   // shadow query: an occluder was found
 
-    bool armed; // begin() left the meshes of this lane's query to the fast BVH (traverse())
+    unsigned long long m_armed;  // wave mask: begin() left the meshes of these lanes' queries to the fast BVH (traverse())
 
     // traversal state of the fast BVH: a local of traverse(), NOT part of the tracer (as members these floats sat in
     // a scratch slot between the calls, loaded at every entry and stored at every exit)
@@ -393,7 +394,7 @@ struct Tracer {
     };
 
     __device__ Tracer(stack_ptr st, Counters &c) : stack(st), cnt(c) {
-        bt = 0; bobj = -1; btri = -1; bprim = -1; bref = EXH; occ = false; armed = false;
+        bt = 0; bobj = -1; btri = -1; bprim = -1; bref = EXH; occ = false; m_armed = 0ull;
     }
 
     // ---- analytic primitives (src/Geometry.hs:68-96) ----
@@ -572,10 +573,17 @@ struct Tracer {
     // light (src/RayHs.hs:74-87).  Planes, spheres and (for the rare rays that need it) the reference
     // tree are finished here; the fast BVH traversal is only armed and runs in traverse().
     __device__ void begin(int kind, const Ray &r, bool point_light, double light_d2) {
-        const bool active = kind != Q_NONE;
-        const bool shadow = kind == Q_SHADOW;
+        typedef unsigned long long mask_t;
+        // (the lanes' kinds as wave masks first, each the ballot of ONE comparison of its own -- the compare then writes the mask itself --
+        // and the lane predicates from the masks: a ballot of a predicate that already has other uses goes through a 0/1 vector register
+        // and a second compare)
+        int kind_ = kind;
+        asm volatile("" : "+v"(kind_));
+        const mask_t m_active = __ballot(kind_ != Q_NONE);
+        const mask_t m_shadow = __ballot(kind_ >= Q_SHADOW);
+        const bool active = __builtin_amdgcn_inverse_ballot_w64(m_active), shadow = __builtin_amdgcn_inverse_ballot_w64(m_shadow);
         if (active) { bt = __builtin_inf(); bobj = -1; btri = -1; bprim = -1; bref = EXH; }
-        armed = false;
+        m_armed = 0ull;
 
         // ---- planes and spheres: wave-uniform loops, scene constants via scalar loads.  Every per-lane yes/no of
         // these loops is a 64-bit WAVE MASK in scalar registers (lane i = bit i), combined with scalar logic and turned
@@ -583,10 +591,7 @@ struct Tracer {
         // As `bool` variables they were kept as 0/1 in vector registers across the loop and re-compared at every use:
         // a dozen vector instructions of bookkeeping per plane beside ~20 of arithmetic.  The only branches are
         // wave-level: nested per-lane ifs cost more scalar exec-mask bookkeeping than the arithmetic they guard.
-        typedef unsigned long long mask_t;
-        const mask_t m_active = __ballot(active);
-        const mask_t m_shadow = __ballot(active && shadow);
-        const mask_t m_point = __ballot(active && shadow && point_light);  // shadow queries towards a point light
+        const mask_t m_point = __ballot(kind_ == Q_SHADOW_POINT);  // shadow queries towards a point light
         mask_t m_occ = 0;  // lanes whose shadow query has found an occluder
         const double a = dot(r.d, r.d);
         // The "beyond the light" shortcut of point-light shadow queries (rounds without such a query skip it).  A plane met at
@@ -601,7 +606,7 @@ struct Tracer {
             const double o_floor = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z)) * 2e-9;
             double k = __builtin_amdgcn_sqrt(light_d2) * 1.006;
             k = o_floor > k ? o_floor : k;  // (a NaN k stays NaN)
-            beyond_k = (active && shadow && point_light && a >= 0.99) ? k : __builtin_inf();  // (per lane: other lanes never pass)
+            beyond_k = (__builtin_amdgcn_inverse_ballot_w64(m_point) && a >= 0.99) ? k : __builtin_inf();  // (per lane: other lanes never pass)
         }
         // (the scene's head -- counts, plane groups, the plane and sphere tables -- in ONE sixteen-dword scalar load: field by field
         // these were eight loads, several of them alone in front of a branch that needs their value)
@@ -614,10 +619,11 @@ struct Tracer {
         // lanes that consider a plane: the closest-hit queries, and the shadow queries still open unless the plane is Emmit
         const mask_t m_closest = EXH ? m_active : (m_active & ~m_shadow);
         mask_t m_shadow_open = EXH ? 0ull : (m_active & m_shadow);  // (shrinks as occluders are found)
-        auto plane_range = [&](auto axis_tag, const int begin_, const int end) {
+        auto plane_range = [&](auto axis_tag, const unsigned begin_off, const unsigned end_off) {
             constexpr int AXIS = decltype(axis_tag)::value;
-            // (the loop runs on the record's byte offset: one scalar add, one compare and the load's own offset operand)
-            for (unsigned off_ = (unsigned)begin_ * (unsigned)sizeof(DPlane); off_ < (unsigned)end * (unsigned)sizeof(DPlane); off_ += (unsigned)sizeof(DPlane)) {
+            // (the loop runs on the record's byte offset -- the group bounds come as byte offsets from the launcher: one scalar add, one compare
+            // and the load's own offset operand)
+            for (unsigned off_ = begin_off; off_ < end_off; off_ += (unsigned)sizeof(DPlane)) {
             unsigned off = off_;
             asm volatile("" : "+s"(off));  // (keeps the offset 32 bits wide: widened, it costs a 64-bit add per plane and a second counter)
             // everything the test reads of the plane, fetched as ONE batch of scalar loads at the top (left to itself the
@@ -664,18 +670,19 @@ struct Tracer {
             }
             }
         };
+        const mask_t m_big = m_active & __ballot(!(magnitude < 1e30));   // (also sends these lanes' meshes to the reference tree below)
         if (m_active != 0ull) {
             // a ray with a non-finite component (0 * inf = NaN in the reference's sums) forces the general form on everyone
-            const bool all_finite = __ballot(active && !(magnitude < 1e30)) == 0ull;
-            const int ex = all_finite ? head[8] : 0, ey = all_finite ? head[9] : 0, ez = all_finite ? head[10] : 0;
-            plane_range(std::integral_constant<int, 0>(), 0, ex);
+            unsigned ex = (unsigned)head[8], ey = (unsigned)head[9], ez = (unsigned)head[10];   // byte offsets where the axis groups end
+            if (m_big != 0ull) ex = ey = ez = 0u;
+            plane_range(std::integral_constant<int, 0>(), 0u, ex);
             plane_range(std::integral_constant<int, 1>(), ex, ey);
             plane_range(std::integral_constant<int, 2>(), ey, ez);
-            plane_range(std::integral_constant<int, 3>(), ez, n_planes);
+            plane_range(std::integral_constant<int, 3>(), ez, (unsigned)n_planes * (unsigned)sizeof(DPlane));
 #ifdef RAYHS_PROBE_PLANES2  // development: what the plane loops cost (they are idempotent: run them twice and compare frame times)
-            { int ex2 = ex, ey2 = ey, ez2 = ez; asm volatile("" : "+s"(ex2), "+s"(ey2), "+s"(ez2));
-              plane_range(std::integral_constant<int, 0>(), 0, ex2); plane_range(std::integral_constant<int, 1>(), ex2, ey2);
-              plane_range(std::integral_constant<int, 2>(), ey2, ez2); plane_range(std::integral_constant<int, 3>(), ez2, n_planes); }
+            { unsigned ex2 = ex, ey2 = ey, ez2 = ez; asm volatile("" : "+s"(ex2), "+s"(ey2), "+s"(ez2));
+              plane_range(std::integral_constant<int, 0>(), 0u, ex2); plane_range(std::integral_constant<int, 1>(), ex2, ey2);
+              plane_range(std::integral_constant<int, 2>(), ey2, ez2); plane_range(std::integral_constant<int, 3>(), ez2, (unsigned)n_planes * (unsigned)sizeof(DPlane)); }
 #endif
         }
         const auto spheres = (cptr<DSphere>)(((unsigned long long)(unsigned)head[3] << 32) | (unsigned long long)(unsigned)head[2]);
@@ -711,11 +718,17 @@ struct Tracer {
             // A ray with a huge or non-finite component goes the same way: the fp32 coordinates of the fast structure could
             // overflow or turn into NaN for it, and its box tests rely on having neither (met()); the reference's answer for a
             // NaN ray -- every comparison false: every box passed, every triangle "hit" -- is its own tree's anyway.
-            const bool by_reference = EXH || !(fabs(r.d.x) > 1e-25) || !(fabs(r.d.y) > 1e-25) || !(fabs(r.d.z) > 1e-25) || !(magnitude < 1e30);  // also keeps 1/d finite in fp32
-            if (EXH || __ballot(active && by_reference) != 0ull)
-                occluded = meshes_reference(active && by_reference, shadow, r, point_light, light_d2, occluded);
+            // (|d| > 1e-25 in every component also keeps 1/d finite in fp32.  All of it on wave masks: as lane predicates the four tests, the
+            // `armed` flag and its ballot in traverse() went through 0/1 vector registers and back)
+            const mask_t m_ref = EXH ? m_active
+                                     : (m_active & (__ballot(!(fabs(r.d.x) > 1e-25)) | __ballot(!(fabs(r.d.y) > 1e-25)) | __ballot(!(fabs(r.d.z) > 1e-25)))) | m_big;
+            mask_t m_occ_now = m_occ;
+            if (m_ref != 0ull) {
+                occluded = meshes_reference(__builtin_amdgcn_inverse_ballot_w64(m_ref), shadow, r, point_light, light_d2, occluded);
+                m_occ_now = __ballot(occluded);
+            }
             // leave the meshes to the fast traversal
-            armed = !EXH && active && !by_reference && !(shadow && occluded);
+            m_armed = EXH ? 0ull : (m_active & ~m_ref & ~(m_shadow & m_occ_now));
         }
         if (active) occ = occluded;
     }
@@ -805,7 +818,6 @@ struct Tracer {
         // (lane yes/no values of the set-up are wave masks in scalar registers, as in begin(): as `bool`s they went through 0/1
         // vector registers and back at every use)
         typedef unsigned long long mask_t;
-        const mask_t m_armed = __ballot(armed);
         if (m_armed == 0ull) return;
         const mask_t m_shadow_q = __ballot(shadow);
         // reciprocal direction in fp32 (1 ulp): every use below is a conservative cull, never a result
@@ -906,17 +918,44 @@ struct Tracer {
                 // trip beside the triangle tests instead of after them -- was tried: the second record's 16 scalar registers on
                 // top of a triangle's 18 spilled 60 more SGPRs into vector lanes, 5.37 -> 5.90 ms.)
                 int cur = me.froot, sp = 0;
+#ifndef RAYHS_EXP_OLD_DISPATCH
+                do {
+#else
                 while (true) {
+#endif
                     LOOP_TICK(40);
+#ifdef RAYHS_PROBE_SALU4   // development: four scalar instructions more per packet visit (+42 M per dragon frame): how does the frame's time answer? (profiles/r06/experiments/)
+                    asm volatile("s_mov_b32 %0, %0\n\ts_mov_b32 %0, %0\n\ts_mov_b32 %0, %0\n\ts_mov_b32 %0, %0" : "+s"(cur));
+#endif
+#ifdef RAYHS_PROBE_VALU4   // ... and four vector instructions more
+                    asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0" : "+v"(limf));
+#endif
 #ifdef RAYHS_PROBE_NODE_FETCH2  // development: what a packet visit's node fetch costs -- a second, DEPENDENT scalar fetch (of the same line: a scalar-cache
                     // hit, ~115 cycles) in front of the real one; profiles/r06/experiments/packet_node_fetch_twice.log
                     cur += *(cptr<int>)((unsigned long long)fnodes + (unsigned long long)((unsigned)cur * (unsigned)sizeof(FNode)) + offsetof(FNode, pad_));  // (pad_ is 0)
 #endif
+#ifndef RAYHS_EXP_NODE_3LOADS
+                    // (the node as ONE sixteen-dword scalar load: left to the compiler -- which only knows the record's 16-byte alignment -- it is
+                    // three, 8 + 4 + 4 dwords: two scalar-memory instructions more per visit, 21 M per dragon frame)
+                    typedef int i16v __attribute__((ext_vector_type(16)));
+                    const i16v raw = *(cptr<i16v>)((unsigned long long)fnodes + (unsigned long long)((unsigned)cur * (unsigned)sizeof(FNode)));
+                    auto fl = [&](int k) { return __builtin_bit_cast(float, (int)raw[k]); };
+                    const float nb0[6] = {fl(0), fl(1), fl(2), fl(3), fl(4), fl(5)}, nb1[6] = {fl(6), fl(7), fl(8), fl(9), fl(10), fl(11)};
+                    const int c0 = raw[12], c1 = raw[13];
+                    static_assert(offsetof(FNode, b1) == 24 && offsetof(FNode, c0) == 48 && offsetof(FNode, c1) == 52 && sizeof(FNode) == 64, "FNode as sixteen dwords");
+#else
                     const auto &nd = crec(fnodes, cur);
                     const int c0 = nd.c0, c1 = nd.c1;
+                    const float *const nb0 = nullptr, *const nb1 = nullptr;
+#endif
                     float tn0, tn1;
+#ifndef RAYHS_EXP_NODE_3LOADS
+                    const unsigned long long b0 = pbox_mask(nb0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0);
+                    const unsigned long long b1 = pbox_mask(nb1, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn1);
+#else
                     const unsigned long long b0 = pbox_mask(nd.b0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0);
                     const unsigned long long b1 = pbox_mask(nd.b1, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn1);
+#endif
                     const unsigned long long m0 = b0 & m_live, m1 = b1 & m_live;  // (an absent child is an empty leaf: no triangles to test)
                     if (COUNT) cnt.c[CNT_NODES] += __builtin_amdgcn_inverse_ballot_w64(m_live) ? (c0 != FNODE_EMPTY) + (c1 != FNODE_EMPTY) : 0;
                     // the child the FIRST lane that meets anything would take first: (ca, ma) before (cb, mb).  One find-first and one
@@ -929,9 +968,78 @@ struct Tracer {
                     unsigned long long ma, mb;
                     asm("s_ff1_i32_b64 %4, %9\n\ts_bitcmp1_b64 %10, %4\n\ts_cselect_b32 %0, %5, %6\n\ts_cselect_b32 %1, %6, %5\n\ts_cselect_b64 %2, %7, %8\n\ts_cselect_b64 %3, %8, %7"
                         : "=&s"(ca), "=&s"(cb), "=&s"(ma), "=&s"(mb), "=&s"(lane1) : "s"(c0), "s"(c1), "s"(m0), "s"(m1), "s"(m_any), "s"(pref0) : "scc");
+#ifndef RAYHS_EXP_OLD_DISPATCH
+                    // What the visit does with its two children, on the scalar unit.  ka / kb: the child if some live lane meets its box, else
+                    // "none" (one compare and one select each).  Leaves are tested at once, nearer one first; then the inner children by three
+                    // selects and compares: the nearer one is walked next, the other pushed when both are inner, a pop when neither is.  The
+                    // walk ends when the stack is empty (cur = none) or no lane is live: ONE condition at the foot of the loop.  (As a loop over
+                    // the two sides with `continue`s, a `next == none` flag and two `break`s, the compiler's structured control flow spent ~20 scalar
+                    // instructions per visit on flags it set, copied and tested again: profiles/r06/isa_mix_by_section_dragon.md.)
+                    const int ka = ma != 0ull ? ca : FNODE_NONE, kb = mb != 0ull ? cb : FNODE_NONE;
+                    auto leaf = [&](const int c, const unsigned long long m_side) {
+                        // leaf: its (<= 3) triangles, each fetched once for the wave; the reference's fp64 test on the ORIGINAL ray
+                        // (every per-lane decision below is a wave mask too: as nested per-lane ifs -- hit, edge band, admitted,
+                        // shadow or closest, the tie chain -- each triangle walked a ladder of six exec-mask levels)
+                        const unsigned long long m_mine = m_side & m_live;
+                        if (m_mine == 0ull) return;
+                        unsigned long long m_leaf_occ = 0;
+                        const int ref = ~c, first = ref >> 3, n = ref & 7;
+                        for (int k = first; k < first + n; k++) {
+                            const auto &tr = crec(ftris, k);
+                            if (COUNT) cnt.c[CNT_TRIS] += __builtin_amdgcn_inverse_ballot_w64(m_mine) ? 1 : 0;
+                            if (__builtin_amdgcn_inverse_ballot_w64(m_mine)) { LOOP_TICK(30); }
+                            double t, u, v;
+                            unsigned long long m_adm = m_mine & tri_test_mask(tr, r, t, u, v);
+                            if (m_adm == 0ull) continue;
+                            const unsigned long long m_edge = m_adm & (__ballot(u < kEdgeBand) | __ballot(v < kEdgeBand) | __ballot((u + v) > 1 - kEdgeBand));
+                            if (m_edge != 0ull) {  // (one hit in a million)
+                                bool admitted = true;
+                                if (__builtin_amdgcn_inverse_ballot_w64(m_edge)) admitted = reference_path_admits(SC.nodes, rec(SC.fattrs, k).leaf_node, r.o, r.d);
+                                m_adm &= __ballot(admitted);
+                            }
+                            const unsigned long long m_sh = m_adm & m_shadow_lanes;
+                            if (m_sh != 0ull) m_leaf_occ |= m_sh & (~m_point_lanes | __ballot(in_front(r, t, true, light_d2)));
+                            const unsigned long long m_cl = m_adm & ~m_shadow_lanes;
+                            if (m_cl != 0ull) {
+                                // offer(): smaller t; at an exact tie the first object, the right-most leaf, the first triangle of a leaf
+                                unsigned long long m_take = __ballot(t < bt);
+                                const unsigned long long m_eq = m_cl & __ballot(t == bt);
+                                if (m_eq != 0ull) {  // (rare: a ray through an edge or a vertex two triangles share)
+                                    int bleaf = -1, brank = -1;
+                                    if (__builtin_amdgcn_inverse_ballot_w64(m_eq) && obj == bobj) {
+                                        const DTri &best = rec(bref ? SC.tris : SC.ftris, btri);
+                                        bleaf = best.leaf_first; brank = best.rank;
+                                    }
+                                    m_take |= m_eq & (__ballot(obj < bobj) | (__ballot(obj == bobj) & (__ballot(tr.leaf_first > bleaf) | (__ballot(tr.leaf_first == bleaf) & __ballot(tr.rank < brank)))));
+                                }
+                                const bool take = __builtin_amdgcn_inverse_ballot_w64(m_take & m_cl);
+                                bt = take ? t : bt; bobj = take ? obj : bobj; btri = take ? k : btri;
+                                bprim = take ? -1 : bprim; bref = take ? false : bref;
+                                limf = take ? f32_up(bt - (double)w.t_enter) : limf;
+                            }
+                        }
+                        m_occ |= m_leaf_occ;
+                        m_live &= ~(m_occ & m_shadow_lanes);  // any occluder settles a shadow query
+                    };
+                    if ((unsigned)ka > (unsigned)FNODE_NONE) leaf(ka, ma);   // (a leaf reference is negative and not "none")
+                    if ((unsigned)kb > (unsigned)FNODE_NONE) leaf(kb, mb);
+                    int next = ka >= 0 ? ka : kb;
+                    if ((ka | kb) >= 0) { wstack[sp * TRACE_BLOCK] = (StackT)kb; sp++; }   // both inner
+                    if (next < 0) {   // neither: the walk goes on with what the stack holds, if anything
+                        next = FNODE_NONE;
+                        if (sp != 0) { sp--; next = __builtin_amdgcn_readfirstlane((int)wstack[sp * TRACE_BLOCK]); }
+                    }
+                    // (one select: a walk none of whose lanes is live any more ends like one whose stack is empty.  In assembly, or the compiler turns
+                    // it back into two conditions, each made a 64-bit mask, and-ed and tested: seven instructions for these three)
+                    asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0x80000000" : "=s"(cur) : "s"(m_live), "s"(next) : "scc");
+                } while (cur >= 0);
+#else
                     int next = FNODE_NONE;
                     // (a visit specialised for "both children are inner nodes" -- no leaf code, three branches instead of ten -- was
                     // measured and dropped: +4 % on the dragon frame, profiles/r04/experiments/visit_variants.log)
+#ifdef RAYHS_EXP_SIDE_ROLLED  // experiment: one copy of the leaf code instead of two (the compiler unrolls this loop and moves the closest-hit record between the copies' registers)
+#pragma nounroll
+#endif
                     for (int side = 0; side < 2; side++) {
                         const int c = side == 0 ? ca : cb;
                         const unsigned long long m_side = side == 0 ? ma : mb;
@@ -995,6 +1103,7 @@ struct Tracer {
                     cur = next;
                     if (m_live == 0ull) break;
                 }
+#endif
                 occ = __builtin_amdgcn_inverse_ballot_w64(m_occ);
                 TIME_ADD(13);
                 continue;
@@ -1037,7 +1146,17 @@ struct Tracer {
                     if ((int)__lane_id() == 0) census_words[threadIdx.x >> 6] = walking;   // (what a sibling that starts a walk now would find here)
                 }
 #endif
+                // (a WAVE-UNIFORM loop -- while some lane still has an inner node to visit and no leaf in hand -- around a per-lane body: as a
+                // per-lane while it cost ~15 instructions of exec-mask loop control per pass, about half of that as a scalar loop)
+#ifdef RAYHS_EXP_UNIFORM_NODE_LOOP   // (measured: +33 M scalar-unit instructions per dragon frame against the per-lane while: profiles/r06/experiments/)
+                while (true) {
+                  const bool go = w.t_cur != FNODE_NONE && w.t_pa == FNODE_NONE;
+                  if (__ballot(go) == 0ull) break;
+                  if (go) {
+#else
                 while (w.t_cur != FNODE_NONE && w.t_pa == FNODE_NONE) {
+                  {
+#endif
                     LOOP_TICK(10);
 #ifdef RAYHS_PROFILE_LOOPS
                     if (COUNT && (int)__lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1) cnt.c[48 + census_bucket]++;   // node-loop iterations of walks of this size
@@ -1057,6 +1176,7 @@ struct Tracer {
                     const int lead = __builtin_amdgcn_readfirstlane(w.t_cur);
                     if (__ballot(w.t_cur != lead) == 0ull) visit(w, as_const(fnodes)[lead], limf);
                     else visit(w, rec(fnodes, w.t_cur), limf);
+                  }
                 }
                 TIME_ADD(13);
                 // phase 2: the postponed leaf, with the reference's fp64 triangle test on the ORIGINAL ray
@@ -1164,9 +1284,8 @@ static __device__ __forceinline__ void trace_body() {
     int fsp = 0;  // suspended irradiance calls = recursion depth of the ray in flight (every frame pushed deepens it by one)
     Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1);
     int qkind = Q_NONE;
-    bool q_point = false; double q_d2 = 0, q_dist = 0;
+    double q_d2 = 0, q_dist = 0;
     int c_obj = 0, c_li = 0;  // object being shaded (its material kind in bits 28..30: the light loop's end asks for it again) and light index
-    bool occluded = false;
 
     // Work items are (pixel, sample) pairs: item / spp is a pixel slot in 8x8-tile order (slot >> 6 = tile,
     // slot & 63 = Morton position in the tile), item % spp the sample.  A wave draws a chunk of 64 consecutive items
@@ -1358,12 +1477,10 @@ static __device__ __forceinline__ void trace_body() {
         // path that reaches the join, and those copies were a quarter of the vector instructions of a round.  The
         // compiler barriers between the sections keep it from turning the LDS hand-over back into register copies.
         TIME_ADD(0);  // refill
-        occluded = tr.occ;
         if (!refilled && state != ST_DONE) {
             LOOP_TICK(16);
             enum : int { A_NONE, A_LIGHT_NEXT, A_SPEC, A_RETURN, A_QUERY_READY };
             int step = A_NONE;
-            bool spec_with_A = false;
 
             if (state == ST_HIT) {
                 LOOP_TICK(24);
@@ -1453,7 +1570,7 @@ static __device__ __forceinline__ void trace_body() {
                 }
             } else if (state == ST_SHADOW) {
                 // accumDiffuse fold step (src/RayHs.hs:90-96)
-                cx_store3(cx, CX_A, add(cx_load3(cx, CX_A), occluded ? mk(0, 0, 0) : LOAD_TERM()));
+                cx_store3(cx, CX_A, add(cx_load3(cx, CX_A), tr.occ ? mk(0, 0, 0) : LOAD_TERM()));
                 c_li++;
                 step = A_LIGHT_NEXT;
             } else if (state == ST_EXIT) {
@@ -1508,16 +1625,31 @@ static __device__ __forceinline__ void trace_body() {
 
             asm volatile("" ::: "memory");
             TIME_ADD(1);  // hit / shadow / exit sections
+            // The loop is WAVE-UNIFORM (it runs while some lane still looks for a light whose term is not zero: more than one pass only then)
+            // around a per-lane body.  As a per-lane do-while with three ways out it cost ~37 scalar instructions of exec-mask bookkeeping
+            // per pass (the structurizer's flags for every exit), 95 M per dragon frame -- more than the loop's arithmetic issues on the
+            // scalar unit (profiles/r06/isa_mix_by_section_dragon.md, segments 210 / 211 / 216 of the basic-block profile).
+#ifdef RAYHS_EXP_UNIFORM_LIGHT_LOOP
+            if (__ballot(step == A_LIGHT_NEXT) != 0ull) {
+                // (every lane reads its slots: the values only matter in the lanes that use them, and a conditional read needs them zeroed first)
+                const V3 c_p = cx_load3(cx, CX_P), c_n = cx_load3(cx, CX_N), c_cd = cx_load3(cx, CX_CD);
+                const int n_lights = SC.n_lights;
+                do {
+                  if (step == A_LIGHT_NEXT) {
+#else
             if (step == A_LIGHT_NEXT) {
                 const V3 c_p = cx_load3(cx, CX_P), c_n = cx_load3(cx, CX_N), c_cd = cx_load3(cx, CX_CD);
                 const int n_lights = SC.n_lights;
-                do {  // per lane; more than one pass only when a light's term is exactly zero
+                do {
+                  {
+#endif
                     LOOP_TICK(26);
                     if (c_li < n_lights) {
                         // lightAt (src/Light.hs:12-17) + diffuse (src/Material.hs:31-33)
                         const DLight L = rec(SC.lights, c_li);  // by value: the whole 64-byte record in one batch of loads, not field by field per branch
                         V3 ld, lc;
-                        if (L.kind == 0) { ld = ld3(L.v); lc = ld3(L.c); q_point = false; q_d2 = 0; q_dist = __builtin_inf(); }
+                        const bool l_point = L.kind != 0;
+                        if (!l_point) { ld = ld3(L.v); lc = ld3(L.c); q_d2 = 0; q_dist = __builtin_inf(); }
                         else {
                             V3 dv = sub(ld3(L.v), c_p);
                             const double d2 = dot(dv, dv);
@@ -1540,7 +1672,7 @@ static __device__ __forceinline__ void trace_body() {
                             }
                             ld = scl(inv_d, dv);
                             lc = scl(falloff, ld3(L.c));
-                            q_point = true; q_dist = d;
+                            q_dist = d;
                         }
                         // the light's diffuse term, added after the shadow query if unoccluded
                         const V3 term = scl(hs_max(dot(ld, c_n), 0) * kPiInv, mulv(c_cd, lc));
@@ -1550,19 +1682,24 @@ static __device__ __forceinline__ void trace_body() {
                         // exhaustive kernels trace it: their work counters are the reference's.)
                         if (!EXH && term.x == 0 && term.y == 0 && term.z == 0) {
                             if (COUNT) { cnt.c[CNT_SHADOW]++; cnt.c[CNT_SHADOW_SKIPPED]++; }
-                            c_li++;
-                            continue;
+                            c_li++;   // (step stays A_LIGHT_NEXT: this lane takes the next pass)
+                        } else {
+                            PARK_TERM(term);
+                            ray.o = add(c_p, scl(kEps, ld)); ray.d = ld;  // rayEps p ld
+                            if (l_point) { V3 dd = sub(ray.o, ld3(L.v)); q_d2 = dot(dd, dd); }  // sqrDist origin p (src/RayHs.hs:87)
+                            if (COUNT) cnt.c[CNT_SHADOW]++;
+                            qkind = l_point ? Q_SHADOW_POINT : Q_SHADOW; state = ST_SHADOW; step = A_QUERY_READY;  // p, n, cd and the running sum A stay parked in LDS
                         }
-                        PARK_TERM(term);
-                        ray.o = add(c_p, scl(kEps, ld)); ray.d = ld;  // rayEps p ld
-                        if (q_point) { V3 dd = sub(ray.o, ld3(L.v)); q_d2 = dot(dd, dd); }  // sqrDist origin p (src/RayHs.hs:87)
-                        if (COUNT) cnt.c[CNT_SHADOW]++;
-                        qkind = Q_SHADOW; state = ST_SHADOW; step = A_QUERY_READY;  // p, n, cd and the running sum A stay parked in LDS
                     } else if ((c_obj >> 28) == 1) {
                         cx_store3(cx, CX_A, add(scl(0.2, c_cd), cx_load3(cx, CX_A)));  // Diffuse (src/RayHs.hs:111-114)
                         step = A_RETURN;
-                    } else { spec_with_A = true; step = A_SPEC; }  // Plastic (src/RayHs.hs:117-120)
+                    } else step = A_SPEC;  // Plastic (src/RayHs.hs:117-120)
+                  }
+#ifdef RAYHS_EXP_UNIFORM_LIGHT_LOOP
+                } while (__ballot(step == A_LIGHT_NEXT) != 0ull);
+#else
                 } while (step == A_LIGHT_NEXT);
+#endif
             }
 
             asm volatile("" ::: "memory");
@@ -1570,6 +1707,7 @@ static __device__ __forceinline__ void trace_body() {
             if (step == A_SPEC) {
                 // fresnel * specular (src/RayHs.hs:99-104,119,124,132)
                 const auto &ob = rec(SC.objects, c_obj & 0x0fffffff);
+                const bool spec_with_A = (c_obj >> 28) == 2;  // Plastic: the light sum in the A slot goes with the reflection (the other ways here -- Mirror, Transparent -- carry none)
                 const V3 c_n = cx_load3(cx, CX_N);
                 V3 c_v = LOAD_V();
                 double F = fresnel(ob.fr, dot(c_n, neg(c_v)), (PRM.flags_dev & 2) != 0);
@@ -1594,15 +1732,23 @@ static __device__ __forceinline__ void trace_body() {
             asm volatile("" ::: "memory");
             TIME_ADD(3);  // specular section
             // hand the radiance in the A slot to the suspended callers until one needs another ray, or the sample is done
+            // (a wave-uniform loop around a per-lane body, like the light section's)
+#ifdef RAYHS_EXP_UNIFORM_LIGHT_LOOP
+            if (__ballot(step == A_RETURN) != 0ull) {
+                V3 result = cx_load3(cx, CX_A);
+                do {
+                  if (step == A_RETURN) {
+#else
             if (step == A_RETURN) {
                 V3 result = cx_load3(cx, CX_A);
-                bool changed = false;
                 do {
+                  {
+#endif
                     LOOP_TICK(28);
                     if (fsp == 0) {
                         const auto &prm = kargs()->prm;
                         if (prm.wave_resolve) {
-                            if (changed) cx_store3(cx, CX_A, result);  // waits in the A slot for the in-wave resolve
+                            cx_store3(cx, CX_A, result);  // waits in the A slot for the in-wave resolve (stored again when nothing was returned to: a flag saying so costs more)
                         } else {
                             int px, lrow, sample;
                             locate(prm, px, lrow, sample);
@@ -1624,7 +1770,6 @@ static __device__ __forceinline__ void trace_body() {
                         const int kind = (int)ws_load(ws, fslot(lv, FS_KIND));
                         const double F = ws_load(ws, fslot(lv, FS_F)), S = ws_load(ws, fslot(lv, FS_S));
                         const V3 fA = ws_load3(ws, fslot(lv, FS_A));
-                        changed = true;
                         if (kind == FR_PLASTIC) {
                             result = add(fA, scl(F, scl(S, result)));
                             fsp = lv;
@@ -1645,7 +1790,12 @@ static __device__ __forceinline__ void trace_body() {
                             fsp = lv;
                         }
                     }
+                  }
+#ifdef RAYHS_EXP_UNIFORM_LIGHT_LOOP
+                } while (__ballot(step == A_RETURN) != 0ull);
+#else
                 } while (step == A_RETURN);
+#endif
             }
 
         }
@@ -1654,9 +1804,10 @@ static __device__ __forceinline__ void trace_body() {
         // parked values in LDS / the workspace instead of forwarding them through registers.
         asm volatile("" ::: "memory");
         TIME_ADD(10);
+        const bool q_point = qkind == Q_SHADOW_POINT;
         tr.begin(qkind, ray, q_point, q_d2);
         TIME_ADD(11);
-        tr.traverse(qkind == Q_SHADOW, ray, q_point, q_d2, q_dist);
+        tr.traverse(qkind >= Q_SHADOW, ray, q_point, q_d2, q_dist);
         TIME_ADD(15);
         asm volatile("" ::: "memory");
     }

@@ -62,7 +62,9 @@ def main():
         m = LOC.match(l)
         if m:
             chain = [(m.group(2), int(m.group(3)))] + [(f, int(n)) for f, n in CHAIN.findall(m.group(4))]
-            cur_loc = [n for f, n in chain if f.endswith("trace_kernel.hip")] or [-1]
+            here = [n for f, n in chain if f.endswith("trace_kernel.hip") and n > 0]
+            if here:              # (line 0 = "no source position": such instructions stay with the position in force before them)
+                cur_loc = here
             out.append(l)
             continue
         if LABEL.match(l):
@@ -93,7 +95,7 @@ def main():
         pending_new = False
         if op == "s_endpgm":
             out += ["\ts_waitcnt lgkmcnt(0)", "\ts_dcache_wb"]
-        segments[-1].append([op, cur_loc])
+        segments[-1].append([op, cur_loc, l.split(";")[0].strip()])
         out.append(l)
         if BRANCH.match(l):
             pending_new = True
