@@ -38,7 +38,8 @@ extern "C" {
  * calls now fail with RAYHS_ERR_INVALID on flag bits the library does not know (RAYHS_FLAG_ALL) instead of ignoring
  * them -- a version-2 library would have rendered the flat-product reading of x ^ 5 for a caller that asked for the other. */
 /* Version 4 changed no struct: it ADDED rayhs_config_reload(), rayhs_scene_capture_tile_order() and rayhs_scene_tile_order(). */
-#define RAYHS_ABI_VERSION 4
+/* Version 5 changed no struct: it ADDED rayhs_selftest_arith(); rayhs_config_reload() became safe beside running entry points. */
+#define RAYHS_ABI_VERSION 5
 
 typedef enum {
     RAYHS_OK = 0,
@@ -194,8 +195,16 @@ int rayhs_device_count(void);
  * diagnostics RAYHS_DEBUG_COUNTERS, RAYHS_DEBUG_TIMING.  A host that changes its environment afterwards calls this to have them read
  * again; safe while other threads are inside the library (they keep the snapshot of the switches they are reading: the new one is
  * swapped in, never written over the old).  (Development knobs -- stack cap, workgroups per CU, dumps, BVH leaf size --
- * exist only in builds made with -DRAYHS_DEV_KNOBS.)  ABI version 4. */
+ * exist only in builds made with -DRAYHS_DEV_KNOBS.)  ABI version 4; safe beside running entry points since version 5. */
 void rayhs_config_reload(void);
+
+/* Diagnostic (ABI version 5): the trace kernels take some fp64 divisions and square roots WITHOUT the range fix-ups of the compiler's
+ * correctly rounded sequences, where the operands' range makes those fix-ups identities (rayhs_amd/csrc/short_div.h).  This runs both
+ * forms on `n` pseudo-random operands per case on `device` and reports, per case, on how many the two differ bit for bit -- zero, or the
+ * shortcut is not exact on this hardware / compiler.  Cases: 0  1/x, |x| in [2^-767, 2^1021];  1  1/x, |x| in [2^-20, 2^366];  2  n/d,
+ * both in [2^-200, 2^200];  3  sqrt x, x in [2^-399, 2^399];  4  sqrt x, x in [2^-767, 2^1023].  RAYHS_ERR_NO_DEVICE without a GPU. */
+#define RAYHS_SELFTEST_ARITH_CASES 5
+int rayhs_selftest_arith(int device, uint64_t n, uint64_t seed, uint64_t mismatches[RAYHS_SELFTEST_ARITH_CASES]);
 
 /* Optional: bring up the HIP runtime, the context of `device` and the kernels' code object now, e.g. from a second host
  * thread while the first one is still decoding the scene -- the first rayhs_scene_create of a process otherwise spends

@@ -35,6 +35,7 @@ hipError_t launch_order_tiles_exact(hipStream_t stream, float *cost, int n, int 
 hipError_t launch_trace_exact(int variant, int grid, size_t lds_bytes, hipStream_t stream, const DScene &sc, const DCamera &cam,
                               const DParams &prm, void *out, unsigned long long *counters, unsigned long long *ticket, double *frames);
 hipError_t launch_warmup_exact(hipStream_t stream);
+hipError_t launch_selftest_arith_exact(hipStream_t stream, unsigned long long *bad, unsigned long long n, unsigned long long seed);
 int occupancy_trace_fast(int variant, size_t lds_bytes);
 int occupancy_trace_exact(int variant, size_t lds_bytes);
 int stack_entry_bytes_fast(int variant);
@@ -173,6 +174,22 @@ extern "C" int rayhs_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+extern "C" int rayhs_selftest_arith(int device, uint64_t n, uint64_t seed, uint64_t mismatches[RAYHS_SELFTEST_ARITH_CASES]) {
+    if (!mismatches || n == 0 || n > (1ULL << 32)) return set_error(RAYHS_ERR_INVALID, "rayhs_selftest_arith: n must be in [1, 2^32] and mismatches not NULL");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return set_error(RAYHS_ERR_NO_DEVICE, "no HIP device");
+    if (device < 0 || device >= count) return set_error(RAYHS_ERR_INVALID, "device %d out of range (%d visible)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, sizeof(uint64_t) * RAYHS_SELFTEST_ARITH_CASES));
+    hipError_t e = hipMemset(d, 0, sizeof(uint64_t) * RAYHS_SELFTEST_ARITH_CASES);
+    if (e == hipSuccess) e = launch_selftest_arith_exact(nullptr, d, n, seed);
+    if (e == hipSuccess) e = hipMemcpy(mismatches, d, sizeof(uint64_t) * RAYHS_SELFTEST_ARITH_CASES, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return set_error(RAYHS_ERR_HIP, "rayhs_selftest_arith failed: %s", hipGetErrorString(e));
+    return RAYHS_OK;
 }
 
 extern "C" int rayhs_device_prepare(int device) {

@@ -893,6 +893,9 @@ struct Tracer {
             // (Walking such a wave as a SEQUENCE of packets, one per bundle of directions, was measured and dropped: +10 % on
             // the dragon frame, +47 % on dragon_low -- profiles/r04/experiments/packet_groups_kbench.log.)
             bool as_packet;
+#ifdef RAYHS_EXP_OCTANT_SPLIT
+            mask_t m_packet = 0ull;   // (the lanes that walk as the packet)
+#endif
             {
                 // (the octant signs and the cone are only looked at by waves that enter: kept out of the code every round runs)
                 float dx = (float)r.d.x, dy = (float)r.d.y, dz = (float)r.d.z;
@@ -905,24 +908,37 @@ struct Tracer {
                 const float lx = __shfl(dx, lead_lane), ly = __shfl(dy, lead_lane), lz = __shfl(dz, lead_lane);
                 const float cosine = (dx * lx + dy * ly + dz * lz) * __builtin_amdgcn_rsqf((dx * dx + dy * dy + dz * dz) * (lx * lx + ly * ly + lz * lz));
                 as_packet = same_octant || (em & ~__ballot(cosine > 0.9f)) == 0ull;
+#ifdef RAYHS_EXP_OCTANT_SPLIT   // experiment: a wave that is no bundle walks its LARGEST octant group as one packet and only the rest per lane
+                if (!as_packet) {
+                    mask_t best = 0ull; int best_n = 0;
+                    for (int o = 0; o < 8; o++) {
+                        const mask_t g = ((o & 1) ? nx : em & ~nx) & ((o & 2) ? ny : em & ~ny) & ((o & 4) ? nz : em & ~nz);
+                        const int n = __popcll(g);
+                        if (n > best_n) { best_n = n; best = g; }
+                    }
+                    if (best_n >= RAYHS_EXP_OCTANT_SPLIT) m_packet = best;
+                }
+#endif
             }
 #ifdef RAYHS_PACKET_ALWAYS
             as_packet = true;
 #endif
+#ifdef RAYHS_EXP_OCTANT_SPLIT
+            if (as_packet) m_packet = em;
+            if (m_packet != 0ull) {
+#else
+            const mask_t m_packet = em;
             if (as_packet) {
+#endif
                 const stack_ptr wstack = stack - (int)(__lane_id());  // lane 0's column serves as the wave's stack
                 // (lane yes/no values are wave masks in scalar registers, as in begin())
-                unsigned long long m_live = em;
+                unsigned long long m_live = m_packet;
                 const unsigned long long m_shadow_lanes = m_shadow_q, m_point_lanes = __ballot(point_light);
                 // (Requesting the next node's record before the leaves of the current visit are tested -- the scalar-cache round
                 // trip beside the triangle tests instead of after them -- was tried: the second record's 16 scalar registers on
                 // top of a triangle's 18 spilled 60 more SGPRs into vector lanes, 5.37 -> 5.90 ms.)
                 int cur = me.froot, sp = 0;
-#ifndef RAYHS_EXP_OLD_DISPATCH
                 do {
-#else
-                while (true) {
-#endif
                     LOOP_TICK(40);
 #ifdef RAYHS_PROBE_SALU4   // development: four scalar instructions more per packet visit (+42 M per dragon frame): how does the frame's time answer? (profiles/r06/experiments/)
                     asm volatile("s_mov_b32 %0, %0\n\ts_mov_b32 %0, %0\n\ts_mov_b32 %0, %0\n\ts_mov_b32 %0, %0" : "+s"(cur));
@@ -934,7 +950,6 @@ struct Tracer {
                     // hit, ~115 cycles) in front of the real one; profiles/r06/experiments/packet_node_fetch_twice.log
                     cur += *(cptr<int>)((unsigned long long)fnodes + (unsigned long long)((unsigned)cur * (unsigned)sizeof(FNode)) + offsetof(FNode, pad_));  // (pad_ is 0)
 #endif
-#ifndef RAYHS_EXP_NODE_3LOADS
                     // (the node as ONE sixteen-dword scalar load: left to the compiler -- which only knows the record's 16-byte alignment -- it is
                     // three, 8 + 4 + 4 dwords: two scalar-memory instructions more per visit, 21 M per dragon frame)
                     typedef int i16v __attribute__((ext_vector_type(16)));
@@ -943,19 +958,9 @@ struct Tracer {
                     const float nb0[6] = {fl(0), fl(1), fl(2), fl(3), fl(4), fl(5)}, nb1[6] = {fl(6), fl(7), fl(8), fl(9), fl(10), fl(11)};
                     const int c0 = raw[12], c1 = raw[13];
                     static_assert(offsetof(FNode, b1) == 24 && offsetof(FNode, c0) == 48 && offsetof(FNode, c1) == 52 && sizeof(FNode) == 64, "FNode as sixteen dwords");
-#else
-                    const auto &nd = crec(fnodes, cur);
-                    const int c0 = nd.c0, c1 = nd.c1;
-                    const float *const nb0 = nullptr, *const nb1 = nullptr;
-#endif
                     float tn0, tn1;
-#ifndef RAYHS_EXP_NODE_3LOADS
                     const unsigned long long b0 = pbox_mask(nb0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0);
                     const unsigned long long b1 = pbox_mask(nb1, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn1);
-#else
-                    const unsigned long long b0 = pbox_mask(nd.b0, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn0);
-                    const unsigned long long b1 = pbox_mask(nd.b1, w.t_ax, w.t_ay, w.t_az, w.t_bx, w.t_by, w.t_bz, limf, tn1);
-#endif
                     const unsigned long long m0 = b0 & m_live, m1 = b1 & m_live;  // (an absent child is an empty leaf: no triangles to test)
                     if (COUNT) cnt.c[CNT_NODES] += __builtin_amdgcn_inverse_ballot_w64(m_live) ? (c0 != FNODE_EMPTY) + (c1 != FNODE_EMPTY) : 0;
                     // the child the FIRST lane that meets anything would take first: (ca, ma) before (cb, mb).  One find-first and one
@@ -968,7 +973,6 @@ struct Tracer {
                     unsigned long long ma, mb;
                     asm("s_ff1_i32_b64 %4, %9\n\ts_bitcmp1_b64 %10, %4\n\ts_cselect_b32 %0, %5, %6\n\ts_cselect_b32 %1, %6, %5\n\ts_cselect_b64 %2, %7, %8\n\ts_cselect_b64 %3, %8, %7"
                         : "=&s"(ca), "=&s"(cb), "=&s"(ma), "=&s"(mb), "=&s"(lane1) : "s"(c0), "s"(c1), "s"(m0), "s"(m1), "s"(m_any), "s"(pref0) : "scc");
-#ifndef RAYHS_EXP_OLD_DISPATCH
                     // What the visit does with its two children, on the scalar unit.  ka / kb: the child if some live lane meets its box, else
                     // "none" (one compare and one select each).  Leaves are tested at once, nearer one first; then the inner children by three
                     // selects and compares: the nearer one is walked next, the other pushed when both are inner, a pop when neither is.  The
@@ -1033,83 +1037,20 @@ struct Tracer {
                     // it back into two conditions, each made a 64-bit mask, and-ed and tested: seven instructions for these three)
                     asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0x80000000" : "=s"(cur) : "s"(m_live), "s"(next) : "scc");
                 } while (cur >= 0);
-#else
-                    int next = FNODE_NONE;
-                    // (a visit specialised for "both children are inner nodes" -- no leaf code, three branches instead of ten -- was
-                    // measured and dropped: +4 % on the dragon frame, profiles/r04/experiments/visit_variants.log)
-#ifdef RAYHS_EXP_SIDE_ROLLED  // experiment: one copy of the leaf code instead of two (the compiler unrolls this loop and moves the closest-hit record between the copies' registers)
-#pragma nounroll
-#endif
-                    for (int side = 0; side < 2; side++) {
-                        const int c = side == 0 ? ca : cb;
-                        const unsigned long long m_side = side == 0 ? ma : mb;
-                        if (m_side == 0ull) continue;
-                        if (c >= 0) {  // inner child: walk it next, or after the first one
-                            if (next == FNODE_NONE) next = c;
-                            else {
-                                wstack[sp * TRACE_BLOCK] = (StackT)c; sp++;
-                            }
-                            continue;
-                        }
-                        // leaf: its (<= 3) triangles, each fetched once for the wave; the reference's fp64 test on the ORIGINAL ray
-                        // (every per-lane decision below is a wave mask too: as nested per-lane ifs -- hit, edge band, admitted,
-                        // shadow or closest, the tie chain -- each triangle walked a ladder of six exec-mask levels)
-                        const unsigned long long m_mine = m_side & m_live;
-                        if (m_mine == 0ull) continue;
-                        unsigned long long m_leaf_occ = 0;
-                        const int ref = ~c, first = ref >> 3, n = ref & 7;
-                        for (int k = first; k < first + n; k++) {
-                            const auto &tr = crec(ftris, k);
-                            if (COUNT) cnt.c[CNT_TRIS] += __builtin_amdgcn_inverse_ballot_w64(m_mine) ? 1 : 0;
-                            if (__builtin_amdgcn_inverse_ballot_w64(m_mine)) { LOOP_TICK(30); }
-                            double t, u, v;
-                            unsigned long long m_adm = m_mine & tri_test_mask(tr, r, t, u, v);
-                            if (m_adm == 0ull) continue;
-                            const unsigned long long m_edge = m_adm & (__ballot(u < kEdgeBand) | __ballot(v < kEdgeBand) | __ballot((u + v) > 1 - kEdgeBand));
-                            if (m_edge != 0ull) {  // (one hit in a million)
-                                bool admitted = true;
-                                if (__builtin_amdgcn_inverse_ballot_w64(m_edge)) admitted = reference_path_admits(SC.nodes, rec(SC.fattrs, k).leaf_node, r.o, r.d);
-                                m_adm &= __ballot(admitted);
-                            }
-                            const unsigned long long m_sh = m_adm & m_shadow_lanes;
-                            if (m_sh != 0ull) m_leaf_occ |= m_sh & (~m_point_lanes | __ballot(in_front(r, t, true, light_d2)));
-                            const unsigned long long m_cl = m_adm & ~m_shadow_lanes;
-                            if (m_cl != 0ull) {
-                                // offer(): smaller t; at an exact tie the first object, the right-most leaf, the first triangle of a leaf
-                                unsigned long long m_take = __ballot(t < bt);
-                                const unsigned long long m_eq = m_cl & __ballot(t == bt);
-                                if (m_eq != 0ull) {  // (rare: a ray through an edge or a vertex two triangles share)
-                                    int bleaf = -1, brank = -1;
-                                    if (__builtin_amdgcn_inverse_ballot_w64(m_eq) && obj == bobj) {
-                                        const DTri &best = rec(bref ? SC.tris : SC.ftris, btri);
-                                        bleaf = best.leaf_first; brank = best.rank;
-                                    }
-                                    m_take |= m_eq & (__ballot(obj < bobj) | (__ballot(obj == bobj) & (__ballot(tr.leaf_first > bleaf) | (__ballot(tr.leaf_first == bleaf) & __ballot(tr.rank < brank)))));
-                                }
-                                const bool take = __builtin_amdgcn_inverse_ballot_w64(m_take & m_cl);
-                                bt = take ? t : bt; bobj = take ? obj : bobj; btri = take ? k : btri;
-                                bprim = take ? -1 : bprim; bref = take ? false : bref;
-                                limf = take ? f32_up(bt - (double)w.t_enter) : limf;
-                            }
-                        }
-                        m_occ |= m_leaf_occ;
-                        m_live &= ~(m_occ & m_shadow_lanes);  // any occluder settles a shadow query
-                    }
-                    if (next == FNODE_NONE) {
-                        if (sp == 0) break;
-                        sp--;
-                        next = __builtin_amdgcn_readfirstlane((int)wstack[sp * TRACE_BLOCK]);
-                    }
-                    cur = next;
-                    if (m_live == 0ull) break;
-                }
-#endif
                 occ = __builtin_amdgcn_inverse_ballot_w64(m_occ);
                 TIME_ADD(13);
+#ifdef RAYHS_EXP_OCTANT_SPLIT
+                if (m_packet == em) continue;
+#else
                 continue;
+#endif
             }
 #endif
+#ifdef RAYHS_EXP_OCTANT_SPLIT
+            if (enter && !__builtin_amdgcn_inverse_ballot_w64(m_packet)) w.t_cur = me.froot;
+#else
             if (enter) w.t_cur = me.froot;
+#endif
             TIME_ADD(12);
 #ifdef RAYHS_PROFILE_LOOPS
             // Census of the per-lane walk (counting kernel of the -DRAYHS_PROFILE_LOOPS build; rows 44..59 of the counters): walks and their
@@ -2102,12 +2043,46 @@ RAYHS_CAT(rayhs_scatter_stripes, RAYHS_KERNEL_SUFFIX)(const char *src, char *dst
     }
 }
 
+// rayhs_selftest_arith (include/rayhs.h): rcp_in_range / div_in_range / sqrt_in_range of short_div.h against the compiler's own correctly
+// rounded sequences, bit for bit, on pseudo-random operands with exponents spread over the ranges the trace kernel uses them in.
+// bad[c]: operands of case c on which the two differ (expected: none).  Cases: 0  1 / x, |x| in [2^-767, 2^1021];  1  1 / x, |x| in
+// [2^-20, 2^366] (the determinant of an accepted triangle);  2  n / d, both in [2^-200, 2^200] (a light's d / radius);  3  sqrt x, x in
+// [2^-399, 2^399] (a light's squared distance behind its range test);  4  sqrt x, x in [2^-767, 2^1023].
+namespace rayhs {
+DEV double selftest_draw(uint64_t i, uint64_t salt, int elo, int ehi, bool positive) {
+    const uint64_t h = mix64(i * 0x9e3779b97f4a7c15ULL + salt);
+    uint64_t mant = h & ((1ULL << 52) - 1);
+    if ((i & 63) == 0) mant = ((h >> 60) & 1) ? (1ULL << 52) - 1 : 0;   // every 64th operand an edge: a power of two, or all ones below it
+    const int e = elo + (int)((h >> 52) % (uint64_t)(ehi - elo + 1));
+    const uint64_t bits = ((positive ? 0ULL : (mix64(h) & 1)) << 63) | ((uint64_t)(e + 1023) << 52) | mant;
+    return __longlong_as_double((long long)bits);
+}
+}  // namespace rayhs
+extern "C" __global__ void __launch_bounds__(256)
+RAYHS_CAT(rayhs_selftest_arith, RAYHS_KERNEL_SUFFIX)(unsigned long long *bad, unsigned long long n, unsigned long long seed) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    auto same = [](double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); };
+    const double x0 = selftest_draw(i, seed + 1, -767, 1021, false), x1 = selftest_draw(i, seed + 2, -20, 366, false);
+    const double d2 = selftest_draw(i, seed + 3, -200, 200, false), n2 = selftest_draw(i, seed + 4, -200, 200, false);
+    const double x3 = selftest_draw(i, seed + 5, -399, 399, true), x4 = selftest_draw(i, seed + 6, -767, 1023, true);
+    if (!same(rcp_in_range(x0), 1.0 / x0)) atomicAdd(&bad[0], 1ULL);
+    if (!same(rcp_in_range(x1), 1.0 / x1)) atomicAdd(&bad[1], 1ULL);
+    if (!same(div_in_range(n2, d2), n2 / d2)) atomicAdd(&bad[2], 1ULL);
+    if (!same(sqrt_in_range(x3), sqrt(x3))) atomicAdd(&bad[3], 1ULL);
+    if (!same(sqrt_in_range(x4), sqrt(x4))) atomicAdd(&bad[4], 1ULL);
+}
+
 // rayhs_device_prepare launches this once: the first launch of a process pays for the compute queue and for putting this
 // translation unit's code object on the device (~20 ms), which a one-shot `rayhs -oX scene.json` can spend while it still parses
 extern "C" __global__ void RAYHS_CAT(rayhs_warmup, RAYHS_KERNEL_SUFFIX)() {}
 
 // Host-side launcher of this translation unit's kernels (called from abi.cpp).
 namespace rayhs {
+hipError_t RAYHS_CAT(launch_selftest_arith, RAYHS_KERNEL_SUFFIX)(hipStream_t stream, unsigned long long *bad, unsigned long long n, unsigned long long seed) {
+    hipLaunchKernelGGL(RAYHS_CAT(rayhs_selftest_arith, RAYHS_KERNEL_SUFFIX), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, bad, n, seed);
+    return hipGetLastError();
+}
 hipError_t RAYHS_CAT(launch_warmup, RAYHS_KERNEL_SUFFIX)(hipStream_t stream) {
     hipLaunchKernelGGL(RAYHS_CAT(rayhs_warmup, RAYHS_KERNEL_SUFFIX), dim3(1), dim3(64), 0, stream);
     return hipGetLastError();

@@ -77,6 +77,7 @@ SYMBOLS = [
     ("rayhs_device_count", C.c_int, []),
     ("rayhs_config_reload", None, []),
     ("rayhs_device_prepare", C.c_int, [C.c_int]),
+    ("rayhs_selftest_arith", C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("rayhs_scene_create", C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
     ("rayhs_scene_destroy", None, [C.c_void_p]),
     ("rayhs_render_rows", C.c_int, [C.POINTER(RenderParams)]),
@@ -106,7 +107,7 @@ SYMBOLS = [
     ("rayhs_sample01", C.c_double, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
 ]
 
-ABI_VERSION = 4   # RAYHS_ABI_VERSION this binding was written against
+ABI_VERSION = 5   # RAYHS_ABI_VERSION this binding was written against
 _LIB = None
 
 

@@ -996,3 +996,15 @@ def test_camera_far_from_a_small_mesh(tmp_path, dist):
     got, want, st, ost = _both(json.dumps(jd), tmp_path)
     assert np.array_equal(got, want) and st["rays"] == ost["rays"]
     assert (want > 0).any(axis=2).sum() > 50
+
+
+def test_short_divisions_and_roots_equal_the_compilers_ieee_sequences_bit_for_bit():
+    # rayhs_amd/csrc/short_div.h: 1/x, n/d and sqrt x without the range fix-ups of the compiler's correctly rounded sequences, used
+    # by the trace kernels where the operands' range makes those fix-ups identities.  2^22 pseudo-random operands per case and seed,
+    # exponents spread over the whole stated range, every 64th a power of two or all-ones mantissa: not one may differ.
+    import ctypes as C
+    lib = L.load()
+    for seed in (1, 0x9e3779b97f4a7c15):
+        out = (C.c_uint64 * 5)()
+        assert lib.rayhs_selftest_arith(0, 1 << 22, seed, out) == 0, lib.rayhs_last_error()
+        assert list(out) == [0, 0, 0, 0, 0], list(out)

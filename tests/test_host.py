@@ -29,7 +29,7 @@ def test_library_is_in_tree_and_exports_every_declared_symbol():
     lib = C.CDLL(L.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert L.load().rayhs_abi_version() == 4
+    assert L.load().rayhs_abi_version() == 5
 
 
 def test_header_is_plain_c_and_a_c_client_links(tmp_path):
@@ -44,7 +44,7 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
                          "-L", bindir, "-lrayhs_hip", "-Wl,-rpath," + bindir], capture_output=True, text=True)
     assert cc.returncode == 0, cc.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert run.returncode == 0 and run.stdout.split()[0] == "4"
+    assert run.returncode == 0 and run.stdout.split()[0] == "5"
 
 
 def test_struct_sizes_match_the_header():
@@ -64,9 +64,9 @@ def test_loader_refuses_a_library_of_another_abi_version_or_layout(monkeypatch):
     # asks for stats (include/rayhs.h, "ABI history").  The binding checks version and struct sizes when it loads.
     monkeypatch.setattr(L, "_LIB", None)
     monkeypatch.setattr(L, "ABI_VERSION", 1)
-    with pytest.raises(ImportError, match="ABI version 4"):
+    with pytest.raises(ImportError, match="ABI version 5"):
         L.load()
-    monkeypatch.setattr(L, "ABI_VERSION", 4)
+    monkeypatch.setattr(L, "ABI_VERSION", 5)
 
     class Stats88(C.Structure):  # the version-1 layout: no shadow_skipped
         _fields_ = L.Stats._fields_[:-1]
@@ -81,7 +81,7 @@ def test_loader_refuses_a_library_of_another_abi_version_or_layout(monkeypatch):
     with pytest.raises(ImportError, match="does not export rayhs_entry_point_of_a_later_version"):
         L.load()
     monkeypatch.undo()
-    assert L.load().rayhs_abi_version() == 4
+    assert L.load().rayhs_abi_version() == 5
 
 
 def test_diagnostic_entry_points_refuse_a_null_scene_without_touching_a_device():
@@ -469,3 +469,13 @@ def test_kernel_source_hash_ignores_comments_but_not_code_behind_an_apostrophe()
     # code behind a digit separator or a stray apostrophe still counts: changing it changes what is hashed
     assert bench._code_only(a.replace("int z = 2;", "int z = 3;")) != got
     assert bench._code_only("x = 1'0; // a\ny = 2;\n") != bench._code_only("x = 1'0; // a\ny = 3;\n")
+
+
+def test_selftest_arith_validates_its_arguments_and_refuses_without_gpu():
+    lib = L.load()
+    out = (C.c_uint64 * 5)()
+    assert lib.rayhs_selftest_arith(0, 0, 1, out) == L.ERR_INVALID            # n = 0
+    assert lib.rayhs_selftest_arith(0, 1 << 33, 1, out) == L.ERR_INVALID      # n beyond 2^32
+    assert lib.rayhs_selftest_arith(0, 1000, 1, None) == L.ERR_INVALID        # nowhere to report
+    if lib.rayhs_device_count() < 1:
+        assert lib.rayhs_selftest_arith(0, 1000, 1, out) == L.ERR_NO_DEVICE

@@ -39,9 +39,8 @@ MARKS = [("(helpers above the tracer)", 1),
          ("visit(): per-lane node visit", find("template <class ND> __device__ __forceinline__ void visit(")),
          ("traverse(): per-mesh set-up, root cull, packet decision", find("__device__ void traverse(bool shadow")),
          ("packet walk: node fetch, two box tests, child order", find("const stack_ptr wstack = stack")),
-         ("packet walk: child dispatch, push", find("for (int side = 0; side < 2; side++) {")),
-         ("packet walk: leaf triangles (fp64 test, masks, tie rule)", find("const unsigned long long m_mine = m_side & m_live;")),
-         ("packet walk: pop / next node", find("if (next == FNODE_NONE) {", find("const unsigned long long m_mine = m_side & m_live;"))),
+         ("packet walk: leaf triangles (fp64 test, masks, tie rule)", find("auto leaf = [&](const int c, const unsigned long long m_side) {")),
+         ("packet walk: inner children (selects), push / pop, loop foot", find("if ((unsigned)ka > (unsigned)FNODE_NONE) leaf(ka, ma);")),
          ("per-lane walk: start, node loop control", find("if (enter) w.t_cur = me.froot;")),
          ("per-lane walk: leaf triangles", find("// phase 2: the postponed leaf")),
          ("per-lane walk: pop, loop end", find("if (w.t_pa == FNODE_NONE && w.t_cur == FNODE_NONE && w.t_sp > 0) {")),

@@ -22,6 +22,7 @@ W = {"dragon": ("scenes/dragon_1080p.json", 16), "dragon_low": ("scenes/dragon_l
 bbmap = json.load(open(os.path.join(os.path.dirname(os.environ["RAYHS_LIB"]), "bbmap.json")))
 STRIDE, NSEG = bbmap["stride_segments"], len(bbmap["segments"])
 WAVES = 8192   # more than any grid this library launches (CUs x 4 workgroups x 4 waves = 4096)
+TAG = os.path.basename(os.path.dirname(os.environ["RAYHS_LIB"]))   # bbprof, or the experiment build's directory (output: gpurun_out/<TAG>_<workload>.json)
 digests = json.load(open("tests/golden/frame_digests.json"))
 os.makedirs("gpurun_out", exist_ok=True)
 for name in (sys.argv[1:] or ["dragon"]):
@@ -53,6 +54,6 @@ for name in (sys.argv[1:] or ["dragon"]):
     res = {"workload": name, "scene": scene, "spp": spp, "frame_ms_instrumented": ms, "frame_sha256_equals_oracle_digest": bool(same),
            "every_counter_a_multiple_of_its_wave_high_word": bool((rem == 0).all()), "waves": waves_used,
            "segment_counts": counts.sum(axis=0).tolist()}
-    json.dump(res, open(f"gpurun_out/bbprof_{name}.json", "w"))
+    json.dump(res, open(f"gpurun_out/{TAG}_{name}.json", "w"))
     print(f"bbprof {name}: {waves_used} waves, {int(counts.sum())} segment executions, frame == oracle digest: {same}, counters exact multiples: {res['every_counter_a_multiple_of_its_wave_high_word']}", flush=True)
     r.close()
