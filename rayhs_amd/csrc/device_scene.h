@@ -68,16 +68,20 @@ struct DSphere {  // src/Geometry.hs:63, 81-96
     double c[3], r2;                // r2 = r ^ 2
     int32_t obj, occluder;
 };
-struct DMesh {
+struct alignas(64) DMesh {
+    // the first 64 bytes are what the fast traversal's per-mesh set-up reads: ONE sixteen-dword scalar load (trace_kernel.hip, traverse())
     int32_t root;                   // reference tree root, -1 = Empty
     int32_t obj, occluder;
     int32_t froot;                  // fast BVH root node, FNODE_NONE = no triangles
-    int32_t tri_base;               // first triangle of this mesh in the BVH-ordered arrays
-    int32_t pad;
-    double lo[3], hi[3];            // the reference root's box (src/KDTree.hs:84)
     double center[3];               // origin of the fp32 box coordinates
     float flo[3], fhi[3];           // bounds of the mesh in those coordinates, rounded outward and inflated
+    // ---- the rest
+    double lo[3], hi[3];            // the reference root's box (src/KDTree.hs:84)
+    int32_t tri_base;               // first triangle of this mesh in the BVH-ordered arrays
+    int32_t pad;
 };
+static_assert(offsetof(DMesh, center) == 16 && offsetof(DMesh, flo) == 40 && offsetof(DMesh, fhi) == 52 && offsetof(DMesh, lo) == 64 && sizeof(DMesh) == 128,
+              "the head of DMesh is one 64-byte fetch");
 struct DObject {  // Material (src/Material.hs:13-19) + ColorMap (src/ColorMap.hs:11-16) of one object
     // the first 64 bytes are what shading a hit reads (DObjectHot): fetched per lane as one batch of four 16-byte loads
     int32_t mat_kind, cmap_kind, tex_w, tex_h;

@@ -623,8 +623,7 @@ struct Tracer {
             constexpr int AXIS = decltype(axis_tag)::value;
             // (the loop runs on the record's byte offset -- the group bounds come as byte offsets from the launcher: one scalar add, one compare
             // and the load's own offset operand)
-            for (unsigned off_ = begin_off; off_ < end_off; off_ += (unsigned)sizeof(DPlane)) {
-            unsigned off = off_;
+            for (unsigned off = begin_off; off < end_off; off += (unsigned)sizeof(DPlane)) {
             asm volatile("" : "+s"(off));  // (keeps the offset 32 bits wide: widened, it costs a 64-bit add per plane and a second counter)
             // everything the test reads of the plane, fetched as ONE batch of scalar loads at the top (left to itself the
             // compiler re-loaded `occluder` and `obj` inside each branch that mentions them: four dependent scalar-cache
@@ -688,7 +687,9 @@ struct Tracer {
         const auto spheres = (cptr<DSphere>)(((unsigned long long)(unsigned)head[3] << 32) | (unsigned long long)(unsigned)head[2]);
         // (a round of shadow queries skips the loop when no sphere can occlude: light bulbs are Emmit)
         const mask_t m_sphere_lanes = (EXH || sphere_occluders != 0) ? m_active : m_closest;
-        for (int i = 0; i < n_spheres && m_sphere_lanes != 0ull; i++) {
+        int n_sph;   // (the loop's trip count as one compare and one select: `i < n && lanes != 0` in its condition was eleven scalar instructions per round)
+        asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(n_sph) : "s"(m_sphere_lanes), "s"(n_spheres) : "scc");
+        for (int i = 0; i < n_sph; i++) {
             // (one batch of scalar loads per sphere, as for the planes)
             struct { double c[3], r2; int obj, occluder; } s;
             { const auto &q = spheres[i]; s.c[0] = q.c[0]; s.c[1] = q.c[1]; s.c[2] = q.c[2]; s.r2 = q.r2; s.obj = q.obj; s.occluder = q.occluder; }
@@ -833,15 +834,17 @@ struct Tracer {
         const FNode *const fnodes = SC.fnodes;
         const DTri *const ftris = SC.ftris;
         for (int m = 0; m < n_meshes; m++) {  // wave-uniform
-            // (what the set-up reads of the mesh record, in one batch of scalar loads)
+            // (what the set-up reads of the mesh record: its first 64 bytes, ONE sixteen-dword scalar load -- field by field they were five)
             struct { int obj, occluder, froot; double center[3]; float flo[3], fhi[3]; } me;
             {
-                const auto &q = meshes[m];
-                me.obj = q.obj; me.occluder = q.occluder; me.froot = q.froot;
-                for (int k = 0; k < 3; k++) { me.center[k] = q.center[k]; me.flo[k] = q.flo[k]; me.fhi[k] = q.fhi[k]; }
+                typedef int i16v __attribute__((ext_vector_type(16)));
+                const i16v raw = *(cptr<i16v>)&meshes[m];
+                me.obj = raw[1]; me.occluder = raw[2]; me.froot = raw[3];
+                for (int k = 0; k < 3; k++) {
+                    me.center[k] = __hiloint2double(raw[5 + 2 * k], raw[4 + 2 * k]);
+                    me.flo[k] = __builtin_bit_cast(float, (int)raw[10 + k]); me.fhi[k] = __builtin_bit_cast(float, (int)raw[13 + k]);
+                }
             }
-            asm volatile("" :: "s"(me.obj), "s"(me.occluder), "s"(me.froot), "s"(me.center[0]), "s"(me.center[1]), "s"(me.center[2]), "s"(me.flo[0]),
-                         "s"(me.flo[1]), "s"(me.flo[2]), "s"(me.fhi[0]), "s"(me.fhi[1]), "s"(me.fhi[2]));
             if (me.froot == FNODE_NONE) continue;
             // a shadow query skips Emmit objects and stops at its first occluder
             unsigned long long m_occ = __ballot(occ);
@@ -998,7 +1001,9 @@ struct Tracer {
                             const unsigned long long m_edge = m_adm & (__ballot(u < kEdgeBand) | __ballot(v < kEdgeBand) | __ballot((u + v) > 1 - kEdgeBand));
                             if (m_edge != 0ull) {  // (one hit in a million)
                                 bool admitted = true;
-                                if (__builtin_amdgcn_inverse_ballot_w64(m_edge)) admitted = reference_path_admits(SC.nodes, rec(SC.fattrs, k).leaf_node, r.o, r.d);
+                                int k_rare = k;
+                                asm volatile("" : "+s"(k_rare));   // (or the loop carries k * sizeof(DTriAttr) along for this one-in-a-million path)
+                                if (__builtin_amdgcn_inverse_ballot_w64(m_edge)) admitted = reference_path_admits(SC.nodes, rec(SC.fattrs, k_rare).leaf_node, r.o, r.d);
                                 m_adm &= __ballot(admitted);
                             }
                             const unsigned long long m_sh = m_adm & m_shadow_lanes;
@@ -1025,8 +1030,10 @@ struct Tracer {
                         m_occ |= m_leaf_occ;
                         m_live &= ~(m_occ & m_shadow_lanes);  // any occluder settles a shadow query
                     };
-                    if ((unsigned)ka > (unsigned)FNODE_NONE) leaf(ka, ma);   // (a leaf reference is negative and not "none")
-                    if ((unsigned)kb > (unsigned)FNODE_NONE) leaf(kb, mb);
+                    if (max((unsigned)ka, (unsigned)kb) > (unsigned)FNODE_NONE) {   // (a leaf reference is negative and not "none"; six visits in seven have none)
+                        if ((unsigned)ka > (unsigned)FNODE_NONE) leaf(ka, ma);
+                        if ((unsigned)kb > (unsigned)FNODE_NONE) leaf(kb, mb);
+                    }
                     int next = ka >= 0 ? ka : kb;
                     if ((ka | kb) >= 0) { wstack[sp * TRACE_BLOCK] = (StackT)kb; sp++; }   // both inner
                     if (next < 0) {   // neither: the walk goes on with what the stack holds, if anything
@@ -1115,7 +1122,14 @@ struct Tracer {
                     // together (55 % of the node-loop iterations on the dragon frame, 72 % at 4K / 64 spp).  Those fetch the
                     // node ONCE through the scalar cache into SGPRs; only diverged waves gather per lane.
                     const int lead = __builtin_amdgcn_readfirstlane(w.t_cur);
-                    if (__ballot(w.t_cur != lead) == 0ull) visit(w, as_const(fnodes)[lead], limf);
+                    if (__ballot(w.t_cur != lead) == 0ull) {   // (the node as ONE sixteen-dword scalar load, as in the packet walk)
+                        typedef int i16v __attribute__((ext_vector_type(16)));
+                        const i16v raw = *(cptr<i16v>)((unsigned long long)fnodes + (unsigned long long)((unsigned)lead * (unsigned)sizeof(FNode)));
+                        struct { float b0[6], b1[6]; int c0, c1; } nd;
+                        for (int k = 0; k < 6; k++) { nd.b0[k] = __builtin_bit_cast(float, (int)raw[k]); nd.b1[k] = __builtin_bit_cast(float, (int)raw[6 + k]); }
+                        nd.c0 = raw[12]; nd.c1 = raw[13];
+                        visit(w, nd, limf);
+                    }
                     else visit(w, rec(fnodes, w.t_cur), limf);
                   }
                 }
