@@ -525,10 +525,12 @@ def main():
                     "valu_pipe": valu, "scalar_unit": scalar,
                     "valu_class_counts": cls, "scalar_unit_insts_per_launch": ctr and ctr.get("scalar_unit_insts_per_launch"),
                     "insts_per_launch": ctr and ctr.get("insts_per_launch"),
-                    "bound_actual": "instruction throughput: the scalar unit of a CU (shared by its 16 resident waves) and the vector pipes are both about two thirds "
-                                    "busy (valu_pipe.frac_measured_costs prices compares, selects and lane reads at the 4 cycles they take back to back, an upper "
-                                    "bound); with 4 waves per SIMD (128 VGPRs of fp64 state) the rest is waits on scalar-cache / LDS / L2 round trips; HBM (3 % of "
-                                    "peak, the scene stays in cache) is nowhere near (DESIGN.md section 4)",
+                    "bound_actual": "latency chains under issue contention: the scalar unit of a CU (shared by its 16 resident waves) and the vector pipes are both about 60 % "
+                                    "busy (valu_pipe.frac_measured_costs prices compares, selects and lane reads at the 4 cycles they take back to back, an upper bound), a wave "
+                                    "issues 37 % of its life and is parked at s_waitcnt 39 %; with 4 waves per SIMD (128 VGPRs of fp64 state, 40 KiB of LDS: both exhausted) the "
+                                    "frame's time follows the length of every wave's chain of dependent steps -- measured on the packet walk: +1 dependent scalar-cache hit per visit "
+                                    "+1.0 %, +4 SALU per visit +0.5 %, +4 VALU +0.3 % (profiles/r06/experiments/); HBM (3 % of peak, the scene stays in cache) is nowhere near "
+                                    "(DESIGN.md section 4)",
                     "scalar_dcache_hit_rate": ctr and ctr.get("scalar_dcache_hit_rate"), "scalar_icache_hit_rate": ctr and ctr.get("scalar_icache_hit_rate"),
                     # SURVEY.md 8(d)'s contract figures: algorithmic bytes / kernel time against the HBM peak (> 1: the bytes are served by the caches)
                     "hbm_contract": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

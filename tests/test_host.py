@@ -479,3 +479,49 @@ def test_selftest_arith_validates_its_arguments_and_refuses_without_gpu():
     assert lib.rayhs_selftest_arith(0, 1000, 1, None) == L.ERR_INVALID        # nowhere to report
     if lib.rayhs_device_count() < 1:
         assert lib.rayhs_selftest_arith(0, 1000, 1, out) == L.ERR_NO_DEVICE
+
+
+def test_basic_block_profiler_rewrite_counts_every_straight_line_segment_once(tmp_path):
+    # tools/bbprof_rewrite.py on a small synthetic listing: one s_atomic_add at the function entry, behind every branch-target label and
+    # behind every conditional branch; every original instruction in exactly one segment; the two scalar registers declared; other kernels untouched
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asm = tmp_path / "dev.s"
+    asm.write_text("\n".join([
+        "other_kernel:", "\ts_endpgm", ".Lfunc_end0:",
+        "rayhs_trace_exact:", ".Lfunc_begin1:",
+        "\t.loc\t2 10 3                          ; rayhs_amd/csrc/trace_kernel.hip:10:3",
+        "\ts_load_dwordx2 s[4:5], s[0:1], 0x1c8",
+        "\tv_mov_b32_e32 v1, 0",
+        ".LBB1_1:                                ; a loop",
+        "\t.loc\t2 0 0                           ; rayhs_amd/csrc/trace_kernel.hip:0:0",
+        "\tv_add_u32_e32 v1, 1, v1",
+        "\t.loc\t2 22 5                          ; rayhs_amd/csrc/trace_kernel.hip:22:5 @[ rayhs_amd/csrc/trace_kernel.hip:40:9 ]",
+        "\ts_cmp_lt_u32 s2, s3",
+        "\ts_cbranch_scc1 .LBB1_1",
+        "\tv_mov_b32_e32 v2, v1",
+        "\ts_endpgm",
+        ".Lfunc_end1:",
+        "\t.amdhsa_kernel rayhs_trace_exact", "\t\t.amdhsa_next_free_sgpr 100", "\t.end_amdhsa_kernel",
+        "\t.set rayhs_trace_exact.numbered_sgpr, max(100, 3)", ""]))
+    spec = importlib.util.spec_from_file_location("bbprof_rewrite", os.path.join(root, "tools", "bbprof_rewrite.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out, mapping = tmp_path / "mod.s", tmp_path / "map.json"
+    argv = ["bbprof_rewrite.py", str(asm), str(out), str(mapping)]
+    old = __import__("sys").argv
+    try:
+        __import__("sys").argv = argv
+        mod.main()
+    finally:
+        __import__("sys").argv = old
+    text = out.read_text()
+    m = json.load(open(mapping))
+    assert text.count("s_atomic_add s101, s[100:101]") == 3 == len(m["segments"])            # entry, the loop's label, behind the conditional branch
+    assert [len(s) for s in m["segments"]] == [2, 3, 2]                                        # every original instruction once
+    assert m["counters_offset"] == 0x1c8 - 16                                                  # KArgs.counters sits 16 bytes in front of KArgs.frames
+    assert m["segments"][1][0][1] == [10]                                                      # a line-0 position keeps the one in force before it
+    assert m["segments"][1][1][1] == [22, 40]                                                  # innermost line first, then its inline callers
+    assert ".amdhsa_next_free_sgpr 102" in text and "numbered_sgpr, max(102," in text
+    assert text.split("rayhs_trace_exact:")[0] == asm.read_text().split("rayhs_trace_exact:")[0]   # the other kernel is untouched
+    assert "s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_endpgm" in text.split("rayhs_trace_exact:")[1]
