@@ -1008,3 +1008,22 @@ def test_short_divisions_and_roots_equal_the_compilers_ieee_sequences_bit_for_bi
         out = (C.c_uint64 * 5)()
         assert lib.rayhs_selftest_arith(0, 1 << 22, seed, out) == 0, lib.rayhs_last_error()
         assert list(out) == [0, 0, 0, 0, 0], list(out)
+
+
+def test_mesh_with_vertex_coordinates_beyond_1e90_is_rendered_by_the_exhaustive_kernel(tmp_path):
+    # The fast walks take 1 / det without the division's range fix-ups, which is the same double only while |det| < 2^1022 -- certain for
+    # vertex coordinates below 1e90 and rays below 1e30, not beyond.  The launcher therefore renders a scene with larger (finite) vertex
+    # coordinates with the exhaustive kernel whatever was asked for (abi.cpp, prepare_launch): same pixels as the oracle, bit for bit,
+    # with the production flags as well as the counting ones.
+    cube = {"geometry": {"type": "mesh", "fileName": "data/cube.obj", "transform": {"type": "scale", "vector": {"x": 1e95, "y": 1e95, "z": 1e95}}},
+            "material": {"type": "diffuse", "cd": {"type": "flat", "color": {"r": 0.9, "g": 0.4, "b": 0.2}}}}
+    jd = json.loads(_scene_json([cube], [DIR, PT], w=24, h=16, depth=1))
+    jd["camera"]["position"] = {"x": 0.1, "y": 0.2, "z": -0.3}
+    p = tmp_path / "s.json"
+    p.write_text(json.dumps(jd))
+    want, ost = oracle_image(str(p))
+    assert (want > 0).any(axis=2).sum() > 50          # the camera sits inside the cube: every ray meets a face ~1e95 away
+    for flags in (PRODUCTION, COUNTING):
+        got, st = rayhs_amd.ray_trace_file(str(p), flags=flags)
+        assert _same(got, want), flags
+    assert st["rays"] == ost["rays"]
