@@ -493,7 +493,7 @@ static int pack_scene(const rayhs_scene_desc *desc, PackedScene &pk) {
             DSphere &s = spheres[(size_t)g];
             for (int c = 0; c < 3; c++) s.c[c] = d.sphere_center[3 * g + c];
             s.r2 = d.sphere_radius[g] * d.sphere_radius[g];  // r ^ 2 (src/Geometry.hs:89)
-            s.obj = i; s.occluder = occl;
+            s.obj = i; s.occluder = occl; s.shadow_skip = occl ? 0ull : ~0ull;
         } else {
             if (mesh_used[(size_t)g]++) return set_error(RAYHS_ERR_INVALID, "mesh %d referenced by two objects", g);
             DMesh &m = meshes[(size_t)g];

@@ -64,10 +64,12 @@ struct alignas(32) DPlane {   // src/Geometry.hs:62, 70-79
     double t[3], b[3];              // b = cross t n (only the UV of a shaded hit reads these)
 };
 static_assert(sizeof(DPlane) == 128, "plane record: 32-byte head + four vectors");
-struct DSphere {  // src/Geometry.hs:63, 81-96
+struct alignas(16) DSphere {  // src/Geometry.hs:63, 81-96.  48 bytes: one eight-dword and one four-dword scalar load per test
     double c[3], r2;                // r2 = r ^ 2
     int32_t obj, occluder;
+    uint64_t shadow_skip;           // occluder ? 0 : ~0, as for the planes: the lanes' "shadow query" mask is and-ed with its complement
 };
+static_assert(sizeof(DSphere) == 48, "sphere record");
 struct alignas(64) DMesh {
     // the first 64 bytes are what the fast traversal's per-mesh set-up reads: ONE sixteen-dword scalar load (trace_kernel.hip, traverse())
     int32_t root;                   // reference tree root, -1 = Empty

@@ -258,6 +258,13 @@ DEV void store_pixel(void *out, int out_format, size_t pix, V3 c) {
     }
 }
 
+// one channel of it (o = 3 * pixel + channel)
+DEV void store_channel(void *out, int out_format, size_t o, double c) {
+    if (out_format == 0) ((float *)out)[o] = (float)c;
+    else if (out_format == 1) ((double *)out)[o] = c;
+    else { const double v = 255 * hs_min(c, 1); ((short *)out)[o] = (short)(v < -32768.0 ? -32768 : (int)v); }
+}
+
 // rare paths kept out of line so that their temporaries do not inflate the kernel's register budget
 struct UV2 { double u, v; };
 static __device__ __attribute__((noinline)) UV2 polar_uv(V3 n) {  // polar, src/Geometry.hs:96 (by value: out-references put u and v of EVERY hit into scratch)
@@ -582,8 +589,11 @@ struct Tracer {
         const mask_t m_active = __ballot(kind_ != Q_NONE);
         const mask_t m_shadow = __ballot(kind_ >= Q_SHADOW);
         const bool active = __builtin_amdgcn_inverse_ballot_w64(m_active), shadow = __builtin_amdgcn_inverse_ballot_w64(m_shadow);
-        if (active) { bt = __builtin_inf(); bobj = -1; btri = -1; bprim = -1; bref = EXH; }
         m_armed = 0ull;
+        // (a round in which no lane asks anything -- the last one of every chunk, whose lanes only store their pixels -- ends here: it ran the
+        // whole preamble, eighty instructions for nobody, 0.52 M times on the dragon frame)
+        if (m_active == 0ull) return;
+        if (active) { bt = __builtin_inf(); bobj = -1; btri = -1; bprim = -1; bref = EXH; }
 
         // ---- planes and spheres: wave-uniform loops, scene constants via scalar loads.  Every per-lane yes/no of
         // these loops is a 64-bit WAVE MASK in scalar registers (lane i = bit i), combined with scalar logic and turned
@@ -670,7 +680,7 @@ struct Tracer {
             }
         };
         const mask_t m_big = m_active & __ballot(!(magnitude < 1e30));   // (also sends these lanes' meshes to the reference tree below)
-        if (m_active != 0ull) {
+        {
             // a ray with a non-finite component (0 * inf = NaN in the reference's sums) forces the general form on everyone
             unsigned ex = (unsigned)head[8], ey = (unsigned)head[9], ez = (unsigned)head[10];   // byte offsets where the axis groups end
             if (m_big != 0ull) ex = ey = ez = 0u;
@@ -687,14 +697,18 @@ struct Tracer {
         const auto spheres = (cptr<DSphere>)(((unsigned long long)(unsigned)head[3] << 32) | (unsigned long long)(unsigned)head[2]);
         // (a round of shadow queries skips the loop when no sphere can occlude: light bulbs are Emmit)
         const mask_t m_sphere_lanes = (EXH || sphere_occluders != 0) ? m_active : m_closest;
-        int n_sph;   // (the loop's trip count as one compare and one select: `i < n && lanes != 0` in its condition was eleven scalar instructions per round)
-        asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(n_sph) : "s"(m_sphere_lanes), "s"(n_spheres) : "scc");
-        for (int i = 0; i < n_sph; i++) {
-            // (one batch of scalar loads per sphere, as for the planes)
-            struct { double c[3], r2; int obj, occluder; } s;
-            { const auto &q = spheres[i]; s.c[0] = q.c[0]; s.c[1] = q.c[1]; s.c[2] = q.c[2]; s.r2 = q.r2; s.obj = q.obj; s.occluder = q.occluder; }
-            asm volatile("" :: "s"(s.c[0]), "s"(s.c[1]), "s"(s.c[2]), "s"(s.r2), "s"(s.obj), "s"(s.occluder));
-            const mask_t m_consider = m_closest | (s.occluder ? m_shadow_open : 0ull);
+        unsigned sph_end;   // (the loop's extent as one compare and one select -- `i < n && lanes != 0` in its condition was eleven scalar instructions per round --
+                            // and in BYTES: the loop counts in the records' offset like the plane loop, one add, one compare and the load's own operand)
+        asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(sph_end) : "s"(m_sphere_lanes), "s"((unsigned)n_spheres * (unsigned)sizeof(DSphere)) : "scc");
+        for (unsigned soff = 0; soff < sph_end; soff += (unsigned)sizeof(DSphere)) {
+            asm volatile("" : "+s"(soff));
+            const int i = (int)(soff / (unsigned)sizeof(DSphere));   // (only a hit asks for it)
+            // (one batch of scalar loads per sphere, as for the planes; "not an occluder" comes as a ready-made mask)
+            struct { double c[3], r2; int obj, occluder; mask_t shadow_skip; } s;
+            { const auto &q = *(cptr<DSphere>)((unsigned long long)spheres + (unsigned long long)soff);
+              s.c[0] = q.c[0]; s.c[1] = q.c[1]; s.c[2] = q.c[2]; s.r2 = q.r2; s.obj = q.obj; s.occluder = q.occluder; s.shadow_skip = q.shadow_skip; }
+            asm volatile("" :: "s"(s.c[0]), "s"(s.c[1]), "s"(s.c[2]), "s"(s.r2), "s"(s.obj), "s"(s.occluder), "s"(s.shadow_skip));
+            const mask_t m_consider = m_closest | (m_shadow_open & ~s.shadow_skip);
             if (m_consider == 0ull) continue;
             if (COUNT) cnt.c[CNT_PRIMS] += __builtin_amdgcn_inverse_ballot_w64(m_consider) ? 1 : 0;
             if (__builtin_amdgcn_inverse_ballot_w64(m_consider)) { LOOP_TICK(22); }
@@ -724,9 +738,14 @@ struct Tracer {
             const mask_t m_ref = EXH ? m_active
                                      : (m_active & (__ballot(!(fabs(r.d.x) > 1e-25)) | __ballot(!(fabs(r.d.y) > 1e-25)) | __ballot(!(fabs(r.d.z) > 1e-25)))) | m_big;
             mask_t m_occ_now = m_occ;
-            if (m_ref != 0ull) {
+            if (__builtin_expect(m_ref != 0ull, 0)) {   // (rare)
                 occluded = meshes_reference(__builtin_amdgcn_inverse_ballot_w64(m_ref), shadow, r, point_light, light_d2, occluded);
                 m_occ_now = __ballot(occluded);
+                // (the hit record leaves this rare branch through an empty asm: its outputs are new values that share registers with the
+                // bypass's, so the copies between the reference walk's registers and the round's stay in here -- they were ten moves on the bypass)
+                int bref_ = bref;
+                asm volatile("" : "+v"(bt), "+v"(bobj), "+v"(btri), "+v"(bprim), "+v"(bref_));
+                bref = bref_ != 0;
             }
             // leave the meshes to the fast traversal
             m_armed = EXH ? 0ull : (m_active & ~m_ref & ~(m_shadow & m_occ_now));
@@ -827,12 +846,15 @@ struct Tracer {
         Walk w;
         w.stop_traversal();
         w.t_ax = w.t_ay = w.t_az = w.t_bx = w.t_by = w.t_bz = w.t_enter = 0;
-        // (read field by field: one eight-dword load of bytes [40, 72) of the scene record was measured 2 % SLOWER here,
-        // profiles/r04/experiments/scene_head_blocks.log)
-        const int n_meshes = SC.n_meshes;
-        const auto meshes = as_const(SC.meshes);
-        const FNode *const fnodes = SC.fnodes;
-        const DTri *const ftris = SC.ftris;
+        // (read field by field, through ONE laundered copy of the kernarg pointer -- each SC.x makes its own, a scalar move apiece.  Block
+        // loads lose here: eight dwords of bytes [40, 72) of the scene record were 2 % SLOWER (profiles/r04/experiments/scene_head_blocks.log),
+        // the ALIGNED eight of bytes [32, 64) saved 8 M scalar instructions on the dragon frame and cost +2 % of its time, +6 % on dragon_low
+        // (profiles/r06/experiments/round_fixed_costs_diet.log): the loop's first branch waits for n_meshes alone)
+        const auto ka_ = kargs();
+        const int n_meshes = ka_->sc.n_meshes;
+        const auto meshes = as_const(ka_->sc.meshes);
+        const FNode *const fnodes = ka_->sc.fnodes;
+        const DTri *const ftris = ka_->sc.ftris;
         for (int m = 0; m < n_meshes; m++) {  // wave-uniform
             // (what the set-up reads of the mesh record: its first 64 bytes, ONE sixteen-dword scalar load -- field by field they were five)
             struct { int obj, occluder, froot; double center[3]; float flo[3], fhi[3]; } me;
@@ -1308,6 +1330,22 @@ static __device__ __forceinline__ void trace_body() {
                 if (prm.wave_resolve && item_valid) {
                     int px, lrow, sample;
                     locate(prm, px, lrow, sample);
+#ifndef RAYHS_NO_CHANNEL_RESOLVE
+                    if (prm.spp >= 4) {
+                        // the pixel's first three lanes take one colour channel each: a third of the additions and of the LDS reads of one
+                        // lane summing all three (every instruction of the sum is issued for the whole wave whichever lanes want it)
+                        if (sample < 3) {
+                            const auto *const col = cx + (CX_A + sample) * TRACE_BLOCK - sample;   // sample k of this lane's pixel and channel: col[k]
+                            double sum = 0;
+#pragma unroll 4
+                            for (int k = 0; k + 4 <= prm.spp; k += 4) {  // foldl (+) black, samples in order (src/RayHs.hs:169-171)
+                                const double a = col[k], b = col[k + 1], c = col[k + 2], d = col[k + 3];   // four at a time: one LDS wait, same order of additions
+                                sum = (((sum + a) + b) + c) + d;
+                            }
+                            store_channel(ptrs.out, prm.out_format, ((size_t)lrow * (size_t)prm.width + (size_t)px) * 3 + (size_t)sample, prm.inv_spp * sum);
+                        }
+                    } else
+#endif
                     if (sample == 0) {
                         V3 sum = mk(0, 0, 0);
                         auto at = [&](int k) { return mk(cx[CX_A * TRACE_BLOCK + k], cx[(CX_A + 1) * TRACE_BLOCK + k], cx[(CX_A + 2) * TRACE_BLOCK + k]); };

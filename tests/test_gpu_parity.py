@@ -226,12 +226,13 @@ def test_two_identical_meshes_tie_goes_to_the_first_object(tmp_path):
 # --------------------------------------------------------------- output formats
 def test_output_formats_f32_and_toIntC_i16():
     r = build_rendering("scenes/cornell_96.json")
-    f64, _ = r.ray_trace(out_format=L.OUT_F64)
-    f32, _ = r.ray_trace(out_format=L.OUT_F32)
-    i16, _ = r.ray_trace(out_format=L.OUT_I16)
-    assert np.array_equal(f32, f64.astype(np.float32))
-    want = np.array([O.lib().orc_to_int_c(float(v)) for v in f64.ravel()], dtype=np.int16).reshape(f64.shape)
-    assert np.array_equal(i16, want)
+    for spp in (1, 2, 16):   # stored by the lane that traced it; folded by one lane per pixel; folded by one lane per pixel and CHANNEL (spp >= 4)
+        f64, _ = r.ray_trace(spp=spp, out_format=L.OUT_F64)
+        f32, _ = r.ray_trace(spp=spp, out_format=L.OUT_F32)
+        i16, _ = r.ray_trace(spp=spp, out_format=L.OUT_I16)
+        assert np.array_equal(f32, f64.astype(np.float32)), spp
+        want = np.array([O.lib().orc_to_int_c(float(v)) for v in f64.ravel()], dtype=np.int16).reshape(f64.shape)
+        assert np.array_equal(i16, want), spp
     r.close()
 
 
