@@ -202,7 +202,7 @@ void rayhs_config_reload(void);
  * correctly rounded sequences, where the operands' range makes those fix-ups identities (rayhs_amd/csrc/short_div.h).  This runs both
  * forms on `n` pseudo-random operands per case on `device` and reports, per case, on how many the two differ bit for bit -- zero, or the
  * shortcut is not exact on this hardware / compiler.  Cases: 0  1/x, |x| in [2^-767, 2^1021];  1  1/x, |x| in [2^-20, 2^366];  2  n/d,
- * both in [2^-200, 2^200];  3  sqrt x, x in [2^-399, 2^399];  4  sqrt x, x in [2^-767, 2^1023].  RAYHS_ERR_NO_DEVICE without a GPU. */
+ * both in [2^-200, 2^200], and +0 / |d|;  3  sqrt x, x in [2^-399, 2^399];  4  sqrt x, x in [2^-767, 2^1023].  RAYHS_ERR_NO_DEVICE without a GPU. */
 #define RAYHS_SELFTEST_ARITH_CASES 5
 int rayhs_selftest_arith(int device, uint64_t n, uint64_t seed, uint64_t mismatches[RAYHS_SELFTEST_ARITH_CASES]);
 

@@ -690,6 +690,10 @@ static void make_camera(const rayhs_camera &c, int width, int height, DCamera &o
     if (aspect > 1) { o.apw = o.w; o.aph = o.w / aspect; } else { o.apw = aspect * o.h; o.aph = o.h; }
     o.f = 0.5 * o.h / (std::tan(0.5) * c.fovy);  // sic: (tan 0.5) * fovy (src/Projection.hs:35)
     o.proj_kind = c.proj_kind;
+    // short_div.h in ray_from_pixel: width, height and the extents are positive and at most 2^24; the numerators are 0 or at least 2^-60 in magnitude;
+    // f (a perspective camera's) must be finite and of moderate size, or the normalisation keeps the compiler's full sequences
+    const double af = std::fabs(o.f);
+    o.short_ok = (c.proj_kind == RAYHS_PROJ_ORTHOGRAPHIC || (std::isfinite(o.f) && af >= 0x1p-300 && af <= 0x1p300)) ? 1 : 0;
 }
 
 // An explicit list of the stripes one launch renders (rayhs_multi: cost-balanced ownership) instead of the round-robin

@@ -141,7 +141,8 @@ struct DCamera {
     double half_w, half_h;  // w/2, h/2
     double apw, aph;      // aspectSize
     double f;             // 0.5 * h / (tan 0.5 * fovy)
-    int32_t proj_kind, pad;
+    int32_t proj_kind;
+    int32_t short_ok;     // the constants are in the range the short division / square root of short_div.h need (make_camera, abi.cpp)
 };
 
 struct DParams {

@@ -302,11 +302,22 @@ constexpr double kEdgeBand = 1e-6;  // barycentric distance from an edge below w
 
 // rayFromPixel (src/Projection.hs:22-39); camera constants precomputed on the host
 template <class CAM> DEV Ray ray_from_pixel(const CAM &c, double px, double py) {
-    double vx = c.apw * (px - c.half_w) / c.w;
-    double vy = c.aph * ((-py) + c.half_h) / c.h;
+    const double nx = c.apw * (px - c.half_w), ny = c.aph * ((-py) + c.half_h);
+    // (the two divisions and the normalisation in their short forms -- short_div.h -- when the launcher found the camera's constants in range,
+    // DCamera::short_ok: 18 vector instructions fewer per chunk of primary rays.  A zero numerator -- the centre column or row -- is +0 here,
+    // x - x, times a positive extent: the short quotient of +0 by a positive divisor is the +0 of the full one)
+    const bool short_ok = kShortDiv && c.short_ok != 0;   // (wave-uniform)
+    double vx, vy;
+    if (short_ok) { vx = div_in_range(nx, c.w); vy = div_in_range(ny, c.h); }
+    else { vx = nx / c.w; vy = ny / c.h; }
     V3 o, d;
     if (c.proj_kind == 0) { o = mk(vx, vy, 0); d = mk(0, 0, 1); }
-    else { d = unit(mk(vx, vy, c.f)); o = mk(0, 0, 0); }
+    else {
+        const V3 v = mk(vx, vy, c.f);
+        const double dd = dot(v, v);
+        d = scl(short_ok ? rcp_in_range(sqrt_in_range(dd)) : 1 / sqrt(dd), v);   // unit, src/Vec.hs:124-126
+        o = mk(0, 0, 0);
+    }
     Ray r;
     r.o = add(o, ld3(c.pos));
     r.d = mk(c.m[0] * d.x + c.m[1] * d.y + c.m[2] * d.z, c.m[3] * d.x + c.m[4] * d.y + c.m[5] * d.z,
@@ -1001,10 +1012,10 @@ struct Tracer {
                     // What the visit does with its two children, on the scalar unit.  ka / kb: the child if some live lane meets its box, else
                     // "none" (one compare and one select each).  Leaves are tested at once, nearer one first; then the inner children by three
                     // selects and compares: the nearer one is walked next, the other pushed when both are inner, a pop when neither is.  The
-                    // walk ends when the stack is empty (cur = none) or no lane is live: ONE condition at the foot of the loop.  (As a loop over
+                    // walk ends when the stack is empty (cur = none); a walk whose last live lane has just been settled empties it (below).  (As a loop over
                     // the two sides with `continue`s, a `next == none` flag and two `break`s, the compiler's structured control flow spent ~20 scalar
                     // instructions per visit on flags it set, copied and tested again: profiles/r06/isa_mix_by_section_dragon.md.)
-                    const int ka = ma != 0ull ? ca : FNODE_NONE, kb = mb != 0ull ? cb : FNODE_NONE;
+                    int ka = ma != 0ull ? ca : FNODE_NONE, kb = mb != 0ull ? cb : FNODE_NONE;
                     auto leaf = [&](const int c, const unsigned long long m_side) {
                         // leaf: its (<= 3) triangles, each fetched once for the wave; the reference's fp64 test on the ORIGINAL ray
                         // (every per-lane decision below is a wave mask too: as nested per-lane ifs -- hit, edge band, admitted,
@@ -1055,6 +1066,10 @@ struct Tracer {
                     if (max((unsigned)ka, (unsigned)kb) > (unsigned)FNODE_NONE) {   // (a leaf reference is negative and not "none"; six visits in seven have none)
                         if ((unsigned)ka > (unsigned)FNODE_NONE) leaf(ka, ma);
                         if ((unsigned)kb > (unsigned)FNODE_NONE) leaf(kb, mb);
+                        // (lanes only leave the walk here -- a shadow query that found its occluder: a walk none of whose lanes is live any more ends
+                        // at once.  The test used to sit at the loop's foot, two scalar instructions on every visit for what one visit in seven can change)
+                        asm("s_cmp_eq_u64 %3, 0\n\ts_cselect_b32 %0, 0x80000000, %0\n\ts_cselect_b32 %1, 0x80000000, %1\n\ts_cselect_b32 %2, 0, %2"
+                            : "+s"(ka), "+s"(kb), "+s"(sp) : "s"(m_live) : "scc");   // (no children, empty stack: the selects below end the walk.  A `break` made the compiler keep a flag)
                     }
                     int next = ka >= 0 ? ka : kb;
                     if ((ka | kb) >= 0) { wstack[sp * TRACE_BLOCK] = (StackT)kb; sp++; }   // both inner
@@ -1062,9 +1077,7 @@ struct Tracer {
                         next = FNODE_NONE;
                         if (sp != 0) { sp--; next = __builtin_amdgcn_readfirstlane((int)wstack[sp * TRACE_BLOCK]); }
                     }
-                    // (one select: a walk none of whose lanes is live any more ends like one whose stack is empty.  In assembly, or the compiler turns
-                    // it back into two conditions, each made a 64-bit mask, and-ed and tested: seven instructions for these three)
-                    asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0x80000000" : "=s"(cur) : "s"(m_live), "s"(next) : "scc");
+                    cur = next;
                 } while (cur >= 0);
                 occ = __builtin_amdgcn_inverse_ballot_w64(m_occ);
                 TIME_ADD(13);
@@ -2098,7 +2111,7 @@ RAYHS_CAT(rayhs_scatter_stripes, RAYHS_KERNEL_SUFFIX)(const char *src, char *dst
 // rayhs_selftest_arith (include/rayhs.h): rcp_in_range / div_in_range / sqrt_in_range of short_div.h against the compiler's own correctly
 // rounded sequences, bit for bit, on pseudo-random operands with exponents spread over the ranges the trace kernel uses them in.
 // bad[c]: operands of case c on which the two differ (expected: none).  Cases: 0  1 / x, |x| in [2^-767, 2^1021];  1  1 / x, |x| in
-// [2^-20, 2^366] (the determinant of an accepted triangle);  2  n / d, both in [2^-200, 2^200] (a light's d / radius);  3  sqrt x, x in
+// [2^-20, 2^366] (the determinant of an accepted triangle);  2  n / d, both in [2^-200, 2^200] (a light's d / radius), every 128th +0 / |d| (a primary ray through the image's centre column);  3  sqrt x, x in
 // [2^-399, 2^399] (a light's squared distance behind its range test);  4  sqrt x, x in [2^-767, 2^1023].
 namespace rayhs {
 DEV double selftest_draw(uint64_t i, uint64_t salt, int elo, int ehi, bool positive) {
@@ -2116,7 +2129,8 @@ RAYHS_CAT(rayhs_selftest_arith, RAYHS_KERNEL_SUFFIX)(unsigned long long *bad, un
     if (i >= n) return;
     auto same = [](double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); };
     const double x0 = selftest_draw(i, seed + 1, -767, 1021, false), x1 = selftest_draw(i, seed + 2, -20, 366, false);
-    const double d2 = selftest_draw(i, seed + 3, -200, 200, false), n2 = selftest_draw(i, seed + 4, -200, 200, false);
+    double d2 = selftest_draw(i, seed + 3, -200, 200, false), n2 = selftest_draw(i, seed + 4, -200, 200, false);
+    if ((i & 127) == 1) { n2 = 0.0; d2 = fabs(d2); }   // (+0 by a positive divisor: the centre column of ray_from_pixel)
     const double x3 = selftest_draw(i, seed + 5, -399, 399, true), x4 = selftest_draw(i, seed + 6, -767, 1023, true);
     if (!same(rcp_in_range(x0), 1.0 / x0)) atomicAdd(&bad[0], 1ULL);
     if (!same(rcp_in_range(x1), 1.0 / x1)) atomicAdd(&bad[1], 1ULL);
