@@ -193,6 +193,22 @@ def test_ragged_sizes_not_multiples_of_the_8x8_tile(tmp_path, w, h):
     assert np.array_equal(got, want) and st["pixels"] == w * h
 
 
+@pytest.mark.parametrize("fovy", [0.9272952180016123, 1e-95, -0.7])
+@pytest.mark.parametrize("proj", ["perspective", "orthographic"])
+def test_primary_rays_with_and_without_the_short_divisions(tmp_path, fovy, proj):
+    # ray_from_pixel divides and normalises in the short forms of short_div.h when the launcher finds the camera constants in range
+    # (DCamera::short_ok) and in the compiler's full sequences otherwise: an ordinary field of view; one whose f = 0.5 h / (tan 0.5 * fovy) lies
+    # beyond 2^300 (a telephoto of all but parallel rays: the full forms); a negative one (the image mirrored: in range).  Even sizes put a pixel
+    # boundary, odd ones a pixel centre on the optical axis: with one sample per pixel the numerator of the centre column / row is exactly +0.
+    big = {"geometry": {"type": "sphere", "center": {"x": 0.5, "y": -0.5, "z": 6}, "radius": 5}, "material": SPH["material"]}   # (an orthographic camera's rays are a pixel apart)
+    for w, h in ((16, 12), (15, 11)):
+        jd = json.loads(_scene_json([SPH, FLOOR, GLASS, big], [PT, DIR], w=w, h=h, proj=proj))
+        jd["camera"]["projection"]["fovy"] = fovy
+        got, want, st, ost = _both(json.dumps(jd), tmp_path)
+        assert _same(got, want) and st["rays"] == ost["rays"], (w, h)
+        assert np.isfinite(want).all() and (want > 0).any()
+
+
 def test_deep_recursion_orthographic_camera_and_directional_light(tmp_path):
     mirror = {"geometry": {"type": "plane", "point": {"x": 0, "y": 0, "z": 2}, "normal": {"x": 0, "y": 0, "z": -1}, "tangent": {"x": 1, "y": 0, "z": 0}},
               "material": {"type": "mirror", "ior": 0.1}}
