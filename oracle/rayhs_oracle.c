@@ -5,7 +5,10 @@
  * reference has no golden vectors and cannot be run here (no GHC).
  *
  * Plain C11, fp64 everywhere, compiled with -ffp-contract=off because GHC does
- * not fuse multiply-add.  Every function cites the reference file:line it
+ * not fuse multiply-add, and with -fno-builtin-sin -fno-builtin-cos because GHC
+ * calls libm's sin and cos each by itself (gcc -O2 merges the pair of a rotation
+ * matrix into sincos(), whose results are not always theirs: oracle/Makefile).
+ * Every function cites the reference file:line it
  * restates (paths relative to /root/reference).  Operation order follows the
  * Haskell source literally: left-associated sums, Haskell min/max semantics,
  * minimumBy's first-wins tie rule, GHC's (^) squaring chain.

@@ -875,9 +875,12 @@ def oracle_image_text(text, tmp_path, **kw):
 from scene_fuzz import rand_scene as _rand_scene  # noqa: E402  (tests/scene_fuzz.py; shared with the CPU differential test of the two restatements)
 
 
+_FUZZ_BASE = int(os.environ.get("RAYHS_FUZZ_SEED_BASE", "0"))   # (a soak over scenes no earlier soak has seen: RAYHS_FUZZ_SEED_BASE=100000)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RAYHS_FUZZ_SEEDS", "24"))))  # RAYHS_FUZZ_SEEDS=400 for a long soak
 def test_random_scenes_bit_exact(tmp_path, seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + _FUZZ_BASE + seed)
     jd = _rand_scene(rng)
     spp = int(rng.choice([1, 1, 2, 3]))
     p = tmp_path / "f.json"
@@ -899,7 +902,7 @@ def test_random_scenes_many_samples_per_pixel_bit_exact(tmp_path, seed):
     # the other end of the work layout: a wave holds the 64 samples of ONE pixel (spp 64), of four (16), or a count
     # that does not divide 64 -- nearly parallel rays, the wave-uniform packet walk and the in-wave sample fold --
     # on random scenes that may hold a 1,700-triangle mesh under a random transform
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + _FUZZ_BASE + seed)
     jd = _rand_scene(rng, more_meshes=("data/dragon_superlow.obj", "data/dragon_superlow.obj"))
     spp = int(rng.choice([16, 64, 7, 96]))
     p = tmp_path / "f.json"

@@ -182,6 +182,25 @@ def test_tree_build_matches_survey_table(mesh):
         assert np.array_equal(pts.min(0), a["node_lo"][k]) and np.array_equal(pts.max(0), a["node_hi"][k])
 
 
+def test_rotations_take_sin_and_cos_by_separate_calls(tmp_path):
+    # gcc -O2 turns sin(a) and cos(a) of one angle into ONE call of glibc's sincos(), whose sine is one ulp off sin()'s for some angles
+    # (this one: found by the round-6 soak over fresh fuzz seeds); GHC calls sin and cos, each by itself (src/Mat.hs:58-74).  Both the oracle
+    # (oracle/Makefile: -fno-builtin-sin -fno-builtin-cos) and the host scene preparation must equal Python's math.sin / math.cos here.
+    import math
+    angle = 0.9261123132458575
+    assert math.sin(angle).hex() == "0x1.993c7fce80301p-1"        # (the sincos() value ends in ...300)
+    obj = tmp_path / "t.obj"
+    obj.write_text("v 1 0 0\nv 0 1 0\nv 0 0 1\nvn 0 0 1\nf 1//1 2//1 3//1\n")
+    for kind, want in (("rotateY", [[math.cos(angle), 0.0, -math.sin(angle)], [0.0, 1.0, 0.0], [math.sin(angle), 0.0, math.cos(angle)]]),
+                       ("rotateX", [[1.0, 0.0, 0.0], [0.0, math.cos(angle), math.sin(angle)], [0.0, -math.sin(angle), math.cos(angle)]]),
+                       ("rotateZ", [[math.cos(angle), math.sin(angle), 0.0], [-math.sin(angle), math.cos(angle), 0.0], [0.0, 0.0, 1.0]])):
+        t = {"type": kind, "angle": angle}
+        host = RenderDesc(text=_mesh_scene(str(obj), t)).arrays()["tri_pos"][0]
+        orc = O.Scene(json.loads(_mesh_scene(str(obj), t))["scene"]).mesh_triangles(0)[0, :, :3]
+        assert np.array_equal(host, np.array(want)), kind      # (the images of the unit vectors are the matrix's columns)
+        assert np.array_equal(orc, np.array(want)), kind
+
+
 def test_rotate_about_axis_and_scale_follow_reference_matrices(tmp_path):
     obj = tmp_path / "t.obj"
     obj.write_text("v 1 0 0\nv 0 1 0\nv 0 0 1\nvn 0 0 1\nf 1//1 2//1 3//1\n")
